@@ -1,0 +1,225 @@
+"""ctypes front-end of the CPU oracle (``libpqd_oracle.so``).
+
+TEST INFRASTRUCTURE ONLY: the oracle is the checker the HIP kernels are compared
+with.  Only tests, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` import this module; the product package never does.
+
+All functions take/return numpy arrays and return ``(status, ...)`` tuples with the
+status codes of ``pqd_oracle.h`` (numerically equal to the ``PQD_*`` codes).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpqd_oracle.so")
+
+OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB = 0, 1, 2, 3, 4, 5
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "pqd_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libpqd_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_szp = C.POINTER(C.c_size_t)
+
+
+def _declare(L):
+    L.orc_unpack8_32.argtypes = [C.c_int, C.c_int, _u8p, _i32p]
+    L.orc_unpack8_32.restype = None
+    L.orc_unpack8_64.argtypes = [C.c_int, C.c_int, _u8p, _i64p]
+    L.orc_unpack8_64.restype = None
+    L.orc_pack8_32.argtypes = [C.c_int, C.c_int, _i32p, _u8p]
+    L.orc_pack8_32.restype = None
+    L.orc_pack8_64.argtypes = [C.c_int, C.c_int, _i64p, _u8p]
+    L.orc_pack8_64.restype = None
+    L.orc_read_batch_i32.argtypes = [C.c_int, _u8p, C.c_size_t, _i32p, C.c_size_t, _szp]
+    L.orc_read_batch_i64.argtypes = [C.c_int, _u8p, C.c_size_t, _i64p, C.c_size_t, _szp]
+    L.orc_rle_decode.argtypes = [C.c_int, _u8p, C.c_size_t, _i32p, C.c_size_t, _szp, _szp]
+    L.orc_rle_prefixed_decode.argtypes = [C.c_int, _u8p, C.c_size_t, _i32p, C.c_size_t, _szp, _szp]
+    L.orc_rle_encode.argtypes = [C.c_int, _i32p, C.c_size_t, _u8p, C.c_size_t]
+    L.orc_rle_encode.restype = C.c_long
+    L.orc_dict_decode_ids.argtypes = [_u8p, C.c_size_t, _i32p, C.c_size_t, _szp]
+    L.orc_dict_decode.argtypes = [_u8p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                  C.c_size_t, _szp]
+    L.orc_dict_encode_ids.argtypes = [_i32p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t]
+    L.orc_dict_encode_ids.restype = C.c_long
+    L.orc_delta_decode.argtypes = [_u8p, C.c_size_t, _i64p, C.c_size_t, _szp, _szp]
+    L.orc_delta_encode_i64.argtypes = [_i64p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
+    L.orc_delta_encode_i64.restype = C.c_long
+    L.orc_delta_encode_i32.argtypes = [_i32p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
+    L.orc_delta_encode_i32.restype = C.c_long
+    L.orc_bss_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_size_t, _u8p, _szp]
+    L.orc_bss_encode.argtypes = [_u8p, C.c_size_t, C.c_int, _u8p]
+    L.orc_bss_encode.restype = None
+    L.orc_bitpacked_levels_decode.argtypes = [C.c_int, _u8p, C.c_size_t, _i32p, C.c_size_t, _szp]
+
+
+def _u8(a):
+    a = np.ascontiguousarray(np.frombuffer(bytes(a), dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a,
+                             dtype=np.uint8)
+    if a.size == 0:
+        a = np.zeros(1, np.uint8)[:0]
+    return a
+
+
+def _p(a, t):
+    if a.size == 0:  # a valid non-null pointer for empty arrays
+        return C.cast(C.create_string_buffer(8), t)
+    return a.ctypes.data_as(t)
+
+
+# ---------------------------------------------------------------- bit packing
+def unpack8(w, data, msb_first=False, long=False):
+    data = _u8(data)
+    out = np.zeros(8, np.int64 if long else np.int32)
+    f = lib().orc_unpack8_64 if long else lib().orc_unpack8_32
+    f(int(msb_first), w, _p(data, _u8p), _p(out, _i64p if long else _i32p))
+    return out
+
+
+def pack8(w, values, msb_first=False, long=False):
+    v = np.ascontiguousarray(values, np.int64 if long else np.int32)
+    out = np.zeros(max(w, 1), np.uint8)
+    f = lib().orc_pack8_64 if long else lib().orc_pack8_32
+    f(int(msb_first), w, _p(v, _i64p if long else _i32p), _p(out, _u8p))
+    return out[:w]
+
+
+def pack(w, values, msb_first=False, long=False):
+    """Pack a multiple-of-8 array with repeated pack8Values."""
+    v = np.ascontiguousarray(values, np.int64 if long else np.int32)
+    assert v.size % 8 == 0
+    out = np.zeros(v.size // 8 * w, np.uint8)
+    for g in range(v.size // 8):
+        out[g * w:(g + 1) * w] = pack8(w, v[g * 8:(g + 1) * 8], msb_first, long)
+    return out
+
+
+def read_batch(w, data, n, long=False):
+    data = _u8(data)
+    out = np.zeros(n, np.int64 if long else np.int32)
+    used = C.c_size_t(0)
+    f = lib().orc_read_batch_i64 if long else lib().orc_read_batch_i32
+    st = f(w, _p(data, _u8p), data.size, _p(out, _i64p if long else _i32p), n, C.byref(used))
+    return st, out, used.value
+
+
+# ---------------------------------------------------------------- RLE hybrid
+def rle_decode(w, data, n, prefixed=False):
+    data = _u8(data)
+    out = np.zeros(n, np.int32)
+    wr, used = C.c_size_t(0), C.c_size_t(0)
+    f = lib().orc_rle_prefixed_decode if prefixed else lib().orc_rle_decode
+    st = f(w, _p(data, _u8p), data.size, _p(out, _i32p), n, C.byref(wr), C.byref(used))
+    return st, out[:wr.value], used.value
+
+
+def rle_encode(w, values):
+    v = np.ascontiguousarray(values, np.int32)
+    cap = v.size * 5 + v.size // 8 + 64
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_rle_encode(w, _p(v, _i32p), v.size, _p(out, _u8p), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+# ---------------------------------------------------------------- dictionary
+def dict_encode_ids(ids, dict_n):
+    v = np.ascontiguousarray(ids, np.int32)
+    cap = v.size * 5 + v.size // 8 + 64
+    out = np.zeros(cap, np.uint8)
+    n = lib().orc_dict_encode_ids(_p(v, _i32p), v.size, dict_n, _p(out, _u8p), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def dict_decode_ids(page, n):
+    page = _u8(page)
+    out = np.zeros(n, np.int32)
+    wr = C.c_size_t(0)
+    st = lib().orc_dict_decode_ids(_p(page, _u8p), page.size, _p(out, _i32p), n, C.byref(wr))
+    return st, out[:wr.value]
+
+
+def dict_decode(page, dictionary, n):
+    page = _u8(page)
+    d = np.ascontiguousarray(dictionary)
+    out = np.zeros(n, d.dtype)
+    wr = C.c_size_t(0)
+    st = lib().orc_dict_decode(_p(page, _u8p), page.size, d.ctypes.data_as(C.c_void_p) if d.size else None,
+                               d.size, d.dtype.itemsize, out.ctypes.data_as(C.c_void_p) if n else None,
+                               n, C.byref(wr))
+    return st, out[:wr.value]
+
+
+# ---------------------------------------------------------------- delta
+def delta_encode(values, block=128, mini=4):
+    v = np.ascontiguousarray(values)
+    assert v.dtype in (np.int32, np.int64)
+    cap = v.size * 10 + 4096
+    out = np.zeros(cap, np.uint8)
+    if v.dtype == np.int64:
+        n = lib().orc_delta_encode_i64(_p(v, _i64p), v.size, block, mini, _p(out, _u8p), cap)
+    else:
+        n = lib().orc_delta_encode_i32(_p(v, _i32p), v.size, block, mini, _p(out, _u8p), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def delta_decode(data, cap):
+    data = _u8(data)
+    out = np.zeros(max(cap, 1), np.int64)
+    total, used = C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_delta_decode(_p(data, _u8p), data.size, _p(out, _i64p), cap, C.byref(total), C.byref(used))
+    n = total.value if st == OK else 0
+    return st, out[:n], total.value, used.value
+
+
+# ---------------------------------------------------------------- byte stream split
+def bss_decode(data, k, bound):
+    data = _u8(data)
+    out = np.zeros(max(data.size, 1), np.uint8)
+    n = C.c_size_t(0)
+    st = lib().orc_bss_decode(_p(data, _u8p), data.size, k, bound, _p(out, _u8p), C.byref(n))
+    return st, out[:n.value * k]
+
+
+def bss_encode(raw, k):
+    raw = _u8(raw)
+    assert raw.size % k == 0
+    out = np.zeros(max(raw.size, 1), np.uint8)
+    lib().orc_bss_encode(_p(raw, _u8p), raw.size // k, k, _p(out, _u8p))
+    return out[:raw.size]
+
+
+# ---------------------------------------------------------------- legacy levels
+def bitpacked_levels_decode(w, data, n):
+    data = _u8(data)
+    out = np.zeros(n, np.int32)
+    used = C.c_size_t(0)
+    st = lib().orc_bitpacked_levels_decode(w, _p(data, _u8p), data.size, _p(out, _i32p), n, C.byref(used))
+    return st, out, used.value

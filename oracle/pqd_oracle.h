@@ -1,0 +1,93 @@
+/*
+ * pqd_oracle.h -- CPU restatement of parquet-java's column-page value decoders.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP kernels are compared
+ * against; nothing in the shipped library links, loads or calls it.  Only the
+ * tests, the smoke check and the benchmark's cpu_baseline leg may use it.
+ *
+ * Every function cites the reference file it restates (paths relative to the
+ * apache/parquet-java tree).  The code is scalar and structured like the Java
+ * (8 values per unpack step, per-run scratch buffers, per-value dictionary
+ * lookup, eager whole-page delta / byte-stream-split decode) so that timing it
+ * gives a fair "restated CPU" baseline.
+ *
+ * Pinning: the functions here are checked in tests/ against every known-answer
+ * vector the reference's own tests hold for this path (bit strings of
+ * TestBitPacking, header bytes and the decoder KAT of
+ * TestRunLengthBitPackingHybridEncoder, float/double vectors of
+ * ByteStreamSplitValuesReaderTest, ...), against the deterministic round-trip
+ * patterns of the reference's tests, and against pages cut out of .parquet
+ * files written by parquet-java itself.
+ */
+#ifndef PQD_ORACLE_H
+#define PQD_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes; numerically identical to the PQD_* codes of include/pqd.h. */
+enum {
+  ORC_OK = 0,
+  ORC_EOF = 1,        /* java.io.EOFException: stream shorter than required          */
+  ORC_BAD_ARG = 2,    /* IllegalArgumentException: bad width / count                 */
+  ORC_PAST_END = 3,   /* "Reading past RLE/BitPacking stream."                       */
+  ORC_DECODE = 4,     /* ParquetDecodingException / AIOOBE on malformed data         */
+  ORC_DICT_OOB = 5    /* dictionary id >= dictionary size                            */
+};
+
+/* ---- bit packing (parquet-generator ByteBasedBitPackingGenerator.java:136-182,224-308) */
+void orc_unpack8_32(int msb_first, int w, const uint8_t* in, int32_t* out);
+void orc_unpack8_64(int msb_first, int w, const uint8_t* in, int64_t* out);
+void orc_pack8_32(int msb_first, int w, const int32_t* in, uint8_t* out);
+void orc_pack8_64(int msb_first, int w, const int64_t* in, uint8_t* out);
+
+/* ParquetReadRouter.readBatch (parquet-plugins/.../ParquetReadRouter.java:107-116) and
+ * readBatchUsing512Vector (:69-104): n (multiple of 8) w-bit LE values. */
+int orc_read_batch_i32(int w, const uint8_t* in, size_t in_len, int32_t* out, size_t n,
+                       size_t* consumed);
+int orc_read_batch_i64(int w, const uint8_t* in, size_t in_len, int64_t* out, size_t n,
+                       size_t* consumed);
+
+/* ---- RLE / bit-packing hybrid (RunLengthBitPackingHybridDecoder.java:52-109) */
+int orc_rle_decode(int w, const uint8_t* in, size_t in_len, int32_t* out, size_t n,
+                   size_t* written, size_t* consumed);
+/* RunLengthBitPackingHybridEncoder.java:146-273; returns encoded length or -1 */
+long orc_rle_encode(int w, const int32_t* v, size_t n, uint8_t* out, size_t cap);
+/* RunLengthBitPackingHybridValuesReader.java:41-45: 4-byte LE length prefix then the stream */
+int orc_rle_prefixed_decode(int w, const uint8_t* in, size_t in_len, int32_t* out, size_t n,
+                            size_t* written, size_t* consumed);
+
+/* ---- dictionary pages (DictionaryValuesReader.java:49-127; writer DictionaryValuesWriter.java:153-180) */
+int orc_dict_decode_ids(const uint8_t* page, size_t len, int32_t* ids, size_t n, size_t* written);
+int orc_dict_decode(const uint8_t* page, size_t len, const void* dict, size_t dict_n,
+                    int elem_size, void* out, size_t n, size_t* written);
+long orc_dict_encode_ids(const int32_t* ids, size_t n, size_t dict_n, uint8_t* out, size_t cap);
+
+/* ---- DELTA_BINARY_PACKED (DeltaBinaryPackingValuesReader.java:60-172) */
+int orc_delta_decode(const uint8_t* in, size_t in_len, int64_t* out, size_t cap,
+                     size_t* total, size_t* consumed);
+/* writers: DeltaBinaryPackingValuesWriterForLong.java:75-184 / ...ForInteger.java:75-182 */
+long orc_delta_encode_i64(const int64_t* v, size_t n, int block, int mini, uint8_t* out, size_t cap);
+long orc_delta_encode_i32(const int32_t* v, size_t n, int block, int mini, uint8_t* out, size_t cap);
+
+/* ---- BYTE_STREAM_SPLIT (ByteStreamSplitValuesReader.java:53-218) */
+int orc_bss_decode(const uint8_t* in, size_t in_len, int k, size_t value_count_bound,
+                   uint8_t* out, size_t* n_values);
+void orc_bss_encode(const uint8_t* in, size_t n, int k, uint8_t* out);
+
+/* ---- legacy BIT_PACKED levels (ByteBitPackingValuesReader.java:41-88), MSB first */
+int orc_bitpacked_levels_decode(int w, const uint8_t* in, size_t in_len, int32_t* out, size_t n,
+                                size_t* consumed);
+
+/* ---- BytesUtils helpers (parquet-common BytesUtils.java:202-269), exposed for tests */
+int orc_read_uvarint32(const uint8_t* in, size_t len, size_t* pos, uint32_t* v);
+int orc_read_zigzag_varlong(const uint8_t* in, size_t len, size_t* pos, int64_t* v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
