@@ -1,0 +1,29 @@
+# Builds the HIP decode library (gfx950 only) and the CPU oracle used by the tests.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+PKG := parquet-java_amd
+CSRC := $(PKG)/csrc
+LIB := $(PKG)/lib/libpqdecode_hip.so
+SRCS := $(CSRC)/pqd_api.hip $(CSRC)/k_unpack.hip $(CSRC)/k_rle.hip $(CSRC)/k_delta.hip $(CSRC)/k_bss.hip
+HDRS := include/pqd.h $(CSRC)/pqd_device.hpp $(CSRC)/pqd_kernels.hpp
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+
+all: $(LIB) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -s -C oracle libpqd_oracle.so
+
+asm: $(SRCS) $(HDRS)
+	@mkdir -p build/asm
+	cd build/asm && for f in k_unpack k_rle k_delta k_bss; do \
+	  $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o $$f.s ../../$(CSRC)/$$f.hip -Rpass-analysis=kernel-resource-usage 2> $$f.usage.txt; done
+
+clean:
+	rm -rf $(PKG)/lib build
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle asm clean

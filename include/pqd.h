@@ -1,0 +1,163 @@
+/*
+ * pqd.h -- C ABI of libpqdecode_hip.so: parquet column-page value decode on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for parquet-java's page-decode path.  Every entry point is
+ * `extern "C"`, takes plain pointers and sizes, and names the reference interface it replaces
+ * (paths relative to the apache/parquet-java tree).  Java binds it through java.lang.foreign
+ * (FFM) or JNI; Python tests bind it through ctypes.
+ *
+ * Conventions
+ *   - Functions return a PQD_* status.  PQD_OK == 0.  No function aborts or throws.
+ *   - "_dev" entry points take DEVICE pointers and enqueue work on `stream` (a hipStream_t passed
+ *     as void*; NULL = the default stream) without synchronising.  Entry points without "_dev"
+ *     take HOST pointers, stage the data through the device and return when the result is in the
+ *     caller's buffer.
+ *   - The library keeps no reference to caller memory after a host entry point returns, or after
+ *     the stream work of a "_dev" entry point has completed.
+ *   - All bit-packed data is parquet's little-endian (LSB-first) packing unless stated otherwise.
+ */
+#ifndef PQD_H
+#define PQD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQD_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes and the Java exception each one stands for ------------------------------ */
+enum pqd_status {
+  PQD_OK = 0,
+  PQD_EOF = 1,       /* java.io.EOFException: fewer bytes than the decode needs                  */
+  PQD_BAD_ARG = 2,   /* IllegalArgumentException: bit width / count outside the contract          */
+  PQD_PAST_END = 3,  /* IllegalArgumentException("Reading past RLE/BitPacking stream.")           */
+  PQD_DECODE = 4,    /* ParquetDecodingException: malformed page                                  */
+  PQD_DICT_OOB = 5,  /* ArrayIndexOutOfBounds -> ParquetDecodingException: id >= dictionary size  */
+  PQD_HIP_ERROR = 6, /* a HIP runtime call failed; see pqd_last_error()                           */
+  PQD_NO_DEVICE = 7  /* no usable gfx950 device                                                  */
+};
+
+/* ---- page encodings (org.apache.parquet.column.Encoding, parquet-column/.../Encoding.java:62-304) */
+enum pqd_encoding {
+  PQD_ENC_RLE = 1,                 /* RLE / bit-packing hybrid -> int32 (levels, booleans, dictionary ids) */
+  PQD_ENC_RLE_DICTIONARY = 2,      /* 1-byte width + hybrid ids, gathered through a dictionary (also PLAIN_DICTIONARY data pages) */
+  PQD_ENC_DELTA_BINARY_PACKED = 3, /* -> int32 / int64 */
+  PQD_ENC_BYTE_STREAM_SPLIT = 4,   /* -> elem_size-byte elements */
+  PQD_ENC_BIT_PACKED = 5           /* legacy MSB-first levels -> int32 */
+};
+
+/* pqd_page_desc.flags */
+#define PQD_F_LENGTH_PREFIX 1u /* PQD_ENC_RLE: 4-byte LE length in front (V1 levels, RLE booleans):
+                                  RunLengthBitPackingHybridValuesReader.java:41-45 */
+#define PQD_F_WIDTH_PREFIX 2u  /* PQD_ENC_RLE: 1-byte bit width in front (dictionary ids as ints):
+                                  DictionaryValuesReader.java:53, readValueDictionaryId :67-73 */
+
+/*
+ * One page (or level stream) to decode.  Replaces ValuesReader.initFromPage(valueCount, stream)
+ * followed by num_values calls of readInteger/readLong/readFloat/readDouble/readValueDictionaryId
+ * (parquet-column/.../values/ValuesReader.java:107-202).  The same struct is used with host
+ * pointers (pqd_decode_page) and device pointers (pqd_decode_pages_dev).
+ */
+typedef struct pqd_page_desc {
+  const uint8_t* data; /* first byte of the stream                                               */
+  void* out;           /* num_values elements of elem_size bytes                                 */
+  const void* dict;    /* PQD_ENC_RLE_DICTIONARY: dict_len values of elem_size bytes (PLAIN
+                          dictionary page body, PlainValuesDictionary.java:148-157,232-241)      */
+  uint32_t data_len;   /* bytes available from `data` (ByteBufferInputStream.available())        */
+  uint32_t num_values; /* values to produce = capacity of `out` in elements.  For the hybrid
+                          encodings: the number of read*() calls; for DELTA / BYTE_STREAM_SPLIT:
+                          the page's valueCount upper bound                                      */
+  uint32_t dict_len;   /* dictionary entries                                                     */
+  uint8_t encoding;    /* enum pqd_encoding                                                      */
+  uint8_t elem_size;   /* bytes per output element: 4 or 8 (BYTE_STREAM_SPLIT: 1..16)            */
+  uint8_t bit_width;   /* PQD_ENC_RLE without WIDTH_PREFIX, PQD_ENC_BIT_PACKED                   */
+  uint8_t flags;       /* PQD_F_*                                                                */
+} pqd_page_desc;
+
+typedef struct pqd_page_result {
+  int32_t status;          /* PQD_* of the first failure in value order, or PQD_OK              */
+  uint32_t values_written; /* leading elements of `out` that are valid                          */
+  uint32_t bytes_consumed; /* stream bytes used (ValuesReader.getNextOffset semantics where the
+                              reference defines them: DELTA_BINARY_PACKED, length-prefixed RLE,
+                              BIT_PACKED, BYTE_STREAM_SPLIT)                                     */
+  uint32_t reserved;
+} pqd_page_result;
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+int pqd_version(void);
+const char* pqd_status_string(int status);
+/* Text of the last failure on the calling thread ("" if none). */
+const char* pqd_last_error(void);
+/* Number of gfx950 devices visible (0 if none / no driver). */
+int pqd_device_count(void);
+/* Makes `device` current for the calling thread and initialises per-device state.
+ * Mirrors the reference's "plugin present?" probe (parquet-encoding/.../Packer.java:68-80,
+ * ParquetReadRouter.java:50-54): PQD_NO_DEVICE plays the role of VectorSupport.NONE. */
+int pqd_init(int device);
+
+int pqd_dev_alloc(void** p, size_t bytes);
+int pqd_dev_free(void* p);
+int pqd_host_alloc_pinned(void** p, size_t bytes);
+int pqd_host_free_pinned(void* p);
+int pqd_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int pqd_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int pqd_memset_dev(void* dst_dev, int value, size_t bytes, void* stream);
+int pqd_stream_create(void** stream);
+int pqd_stream_destroy(void* stream);
+int pqd_stream_sync(void* stream);
+/* HIP events on the library's streams (for timing the kernels where they run). */
+int pqd_event_create(void** ev);
+int pqd_event_destroy(void* ev);
+int pqd_event_record(void* ev, void* stream);
+int pqd_event_sync(void* ev);
+int pqd_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* ---- bulk bit-unpack: one bit-packed run --------------------------------------------------- */
+/*
+ * Replaces ParquetReadRouter.read / readBatchUsing512Vector / readBatch(bitWidth, in,
+ * currentCount, currentBuffer)  (parquet-plugins/parquet-encoding-vector/.../ParquetReadRouter.java:57-116)
+ * and, per step, BytePacker.unpack8Values / unpack32Values / unpackValuesUsingVector
+ * (parquet-encoding/.../BytePacker.java:87-148).
+ * n_values must be a multiple of 8; bit_width 0..32; exactly n_values*bit_width/8 bytes are
+ * consumed; PQD_EOF if in_len is smaller (the Java in.slice() throws EOFException).
+ * Width 32 returns raw bit patterns (negative ints are legal).
+ */
+int pqd_unpack_i32(int bit_width, const uint8_t* in, size_t in_len, int32_t* out, size_t n_values);
+int pqd_unpack_i32_dev(int bit_width, const uint8_t* in, size_t in_len, int32_t* out, size_t n_values,
+                       void* stream);
+/* BytePackerForLong.unpack8Values / unpack32Values over a whole run, widths 0..64
+ * (parquet-encoding/.../BytePackerForLong.java:72-105). */
+int pqd_unpack_i64(int bit_width, const uint8_t* in, size_t in_len, int64_t* out, size_t n_values);
+int pqd_unpack_i64_dev(int bit_width, const uint8_t* in, size_t in_len, int64_t* out, size_t n_values,
+                       void* stream);
+
+/* ---- page decode ---------------------------------------------------------------------------- */
+/*
+ * Device-resident batch: `descs` and `results` are DEVICE arrays of n_pages entries whose
+ * data/out/dict members are device pointers.  One workgroup decodes one page.  All pages of one
+ * call must share `encoding` and `elem_size` (one launch per encoding class); a descriptor that
+ * disagrees gets PQD_BAD_ARG in its result.  Replaces, per page, Encoding.getValuesReader /
+ * getDictionaryBasedValuesReader + initFromPage + read loop as driven by
+ * ColumnReaderBase.initDataReader/readPageV1/readPageV2 (parquet-column/.../impl/ColumnReaderBase.java:693-780).
+ */
+int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,
+                         int elem_size, void* stream);
+/*
+ * Host-side batch: `descs`/`results` are HOST arrays, but data/out/dict are still device pointers.
+ * Groups the pages by encoding class, uploads the descriptors, launches, downloads the results and
+ * synchronises `stream`.
+ */
+int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream);
+/*
+ * One page, everything in host memory (what a Java ValuesReader subclass calls from
+ * initFromPage): stages data (+ dictionary) to the device, decodes, copies `out` back.
+ */
+int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQD_H */

@@ -1,0 +1,437 @@
+"""parquet page decode on MI355X -- host-side mirror of parquet-java's reader interface.
+
+The classes here keep the names, argument meaning and failure behaviour of the reference's
+``ParquetReadRouter`` / ``ValuesReader`` surface and forward every decode to the HIP library through
+its C ABI (``include/pqd.h``).  They exist so callers (and the parity tests) can be written the way
+the reference's own callers are; the compute is in ``csrc/*.hip``.  There is no CPU decode path in
+this package.
+
+Reference (paths relative to the parquet-java tree):
+  parquet-plugins/parquet-encoding-vector/.../ParquetReadRouter.java:57-116
+  parquet-column/.../column/values/ValuesReader.java:36-203
+  parquet-common/.../bytes/ByteBufferInputStream.java:35-151
+"""
+import ctypes as _C
+
+import numpy as _np
+
+from . import _native
+from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
+                      ENC_DELTA_BINARY_PACKED, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
+                      HIP_ERROR, NO_DEVICE, OK, PAST_END, PageDesc, PageResult, PqdError, check, lib)
+
+__all__ = ["ParquetReadRouter", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
+           "DictionaryValuesReader", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader",
+           "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
+           "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
+
+
+# ------------------------------------------------------------------------------- exceptions
+class ParquetDecodingException(RuntimeError):
+    """org.apache.parquet.io.ParquetDecodingException"""
+
+
+class EOFException(EOFError):
+    """java.io.EOFException"""
+
+
+class IllegalArgumentException(ValueError):
+    """java.lang.IllegalArgumentException"""
+
+
+def _raise_for(status, what=""):
+    if status == OK:
+        return
+    if status == EOF:
+        raise EOFException(what)
+    if status == BAD_ARG:
+        raise IllegalArgumentException(what or lib.pqd_last_error().decode())
+    if status == PAST_END:
+        raise IllegalArgumentException("Reading past RLE/BitPacking stream.")
+    if status in (DECODE, DICT_OOB):
+        raise ParquetDecodingException(what or lib.pqd_status_string(status).decode())
+    raise PqdError(status, what)
+
+
+def device_count():
+    return lib.pqd_device_count()
+
+
+def init(device=0):
+    check(lib.pqd_init(device), "pqd_init")
+
+
+# ------------------------------------------------------------------------------- streams
+class ByteBufferInputStream:
+    """The slice of ByteBufferInputStream the decoders use (single-buffer flavour:
+    parquet-common/.../bytes/SingleBufferInputStream.java:43-177)."""
+
+    def __init__(self, buf, start=0, end=None):
+        self._buf = _np.frombuffer(bytes(buf), dtype=_np.uint8) if not isinstance(buf, _np.ndarray) else buf
+        self._start = start
+        self._pos = start
+        self._end = self._buf.size if end is None else end
+
+    @staticmethod
+    def wrap(buf):
+        return ByteBufferInputStream(buf)
+
+    def position(self):
+        return self._pos - self._start
+
+    def available(self):
+        return self._end - self._pos
+
+    def read(self):
+        if self._pos >= self._end:
+            raise EOFException()
+        b = int(self._buf[self._pos])
+        self._pos += 1
+        return b
+
+    def skipFully(self, n):
+        if n > self.available():
+            raise EOFException()
+        self._pos += n
+
+    def slice(self, length):
+        if self.available() < length:
+            raise EOFException()
+        out = self._buf[self._pos:self._pos + length]
+        self._pos += length
+        return out
+
+    def sliceStream(self, length):
+        if self.available() < length:
+            raise EOFException()
+        s = ByteBufferInputStream(self._buf, self._pos, self._pos + length)
+        self._pos += length
+        return s
+
+    def remainingStream(self):
+        return self.sliceStream(self.available())
+
+    def _peek_all(self):
+        return self._buf[self._pos:self._end]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_C.c_void_p) if a.size else None
+
+
+# ------------------------------------------------------------------------------- ParquetReadRouter
+class ParquetReadRouter:
+    """Bulk unpack of one bit-packed run into ``currentBuffer[0:currentCount]``.
+
+    Same contract as ParquetReadRouter.read / readBatchUsing512Vector / readBatch
+    (ParquetReadRouter.java:57-116): consumes exactly ``currentCount*bitWidth/8`` bytes of ``in``,
+    EOFException if fewer remain.  All three names run the device kernel (``pqd_unpack_i32``).
+    """
+
+    @staticmethod
+    def read(bitWidth, in_, currentCount, currentBuffer):
+        total = currentCount * bitWidth // 8
+        buf = _np.ascontiguousarray(in_.slice(total))  # EOFException if short, as the Java slice()
+        out = currentBuffer
+        if not (isinstance(out, _np.ndarray) and out.dtype == _np.int32 and out.flags.c_contiguous):
+            raise IllegalArgumentException("currentBuffer must be a contiguous int32 array")
+        if out.size < currentCount:
+            raise IndexError("currentBuffer too small")  # ArrayIndexOutOfBoundsException
+        st = lib.pqd_unpack_i32(bitWidth, _ptr(buf), buf.size, _ptr(out), currentCount)
+        _raise_for(st, "ParquetReadRouter.read")
+
+    readBatchUsing512Vector = read
+    readBatch = read
+
+    @staticmethod
+    def readLongs(bitWidth, in_, currentCount, currentBuffer):
+        """BytePackerForLong.unpack8Values over a whole run (BytePackerForLong.java:72-105)."""
+        total = currentCount // 8 * bitWidth
+        buf = _np.ascontiguousarray(in_.slice(total))
+        st = lib.pqd_unpack_i64(bitWidth, _ptr(buf), buf.size, _ptr(currentBuffer), currentCount)
+        _raise_for(st, "ParquetReadRouter.readLongs")
+
+
+# ------------------------------------------------------------------------------- ValuesReader family
+class ValuesReader:
+    """Eager page reader: ``initFromPage`` decodes the page on the device (``pqd_decode_page``),
+    ``read*()`` serve from the decoded array, failures surface at the read that would have
+    raised them in the reference (ValuesReader.java:107-202)."""
+
+    _encoding = None
+    _dtype = _np.int32
+    _flags = 0
+    _bit_width = 0
+
+    def __init__(self):
+        self._values = _np.zeros(0, self._dtype)
+        self._status = OK
+        self._i = 0
+        self._next_offset = None
+
+    # -- the part subclasses parameterise
+    def _dict_array(self):
+        return None
+
+    def _elem_size(self):
+        return _np.dtype(self._dtype).itemsize
+
+    def initFromPage(self, valueCount, stream):
+        start = stream.position()
+        data = _np.ascontiguousarray(stream._peek_all())
+        out = _np.zeros(max(valueCount, 1) * self._elem_size(), _np.uint8)
+        d = PageDesc()
+        d.data = data.ctypes.data if data.size else None
+        d.data_len = data.size
+        d.out = out.ctypes.data
+        d.num_values = valueCount
+        d.encoding = self._encoding
+        d.elem_size = self._elem_size()
+        d.bit_width = self._bit_width
+        d.flags = self._flags
+        dic = self._dict_array()
+        if dic is not None:
+            d.dict = dic.ctypes.data if dic.size else None
+            d.dict_len = dic.size
+        r = PageResult()
+        check(lib.pqd_decode_page(_C.byref(d), _C.byref(r)), "pqd_decode_page")
+        self._status = r.status
+        self._values = out[:r.values_written * self._elem_size()].view(self._dtype) if self._elem_size() in (1, 2, 4, 8) \
+            else out[:r.values_written * self._elem_size()].reshape(-1, self._elem_size())
+        self._i = 0
+        self._consume(stream, r, start)
+
+    def _consume(self, stream, r, start):
+        stream.skipFully(stream.available())  # hybrid readers take the rest of the page
+
+    def getNextOffset(self):
+        if self._next_offset is None:
+            raise ParquetDecodingException("Unsupported: cannot get offset of the next section.")
+        return self._next_offset
+
+    def _next(self):
+        if self._i >= len(self._values):
+            self._fail_at_end()
+        v = self._values[self._i]
+        self._i += 1
+        return v
+
+    def _fail_at_end(self):
+        _raise_for(self._status if self._status != OK else PAST_END)
+
+    def readInteger(self):
+        return int(self._next())
+
+    def readLong(self):
+        return int(self._next())
+
+    def readFloat(self):
+        return float(self._next())
+
+    def readDouble(self):
+        return float(self._next())
+
+    def readBoolean(self):
+        return self.readInteger() != 0
+
+    def readValueDictionaryId(self):
+        return self.readInteger()
+
+    def skip(self, n=1):
+        for _ in range(n):
+            self._next()
+
+    def values(self):
+        """All decoded values (not part of the reference interface; bulk access for columnar callers)."""
+        return self._values
+
+
+class RunLengthBitPackingHybridValuesReader(ValuesReader):
+    """RunLengthBitPackingHybridValuesReader.java:31-66: 4-byte length prefix, then the hybrid stream."""
+    _encoding = ENC_RLE
+    _flags = F_LENGTH_PREFIX
+
+    def __init__(self, bitWidth):
+        super().__init__()
+        self._bit_width = bitWidth
+
+    def initFromPage(self, valueCount, stream):
+        if stream.available() < 4:
+            raise EOFException()
+        super().initFromPage(valueCount, stream)
+
+    def _consume(self, stream, r, start):
+        if r.status in (EOF, DECODE) and r.values_written == 0 and r.bytes_consumed == 0:
+            _raise_for(r.status)  # sliceStream(length) failed inside initFromPage
+        stream.skipFully(r.bytes_consumed)
+        self._next_offset = r.bytes_consumed
+
+
+class RunLengthBitPackingHybridDecoder(ValuesReader):
+    """Bare hybrid stream of known width (V2 levels: ColumnReaderBase.java:770-780)."""
+    _encoding = ENC_RLE
+
+    def __init__(self, bitWidth, stream=None, valueCount=0):
+        super().__init__()
+        if not 0 <= bitWidth <= 32:
+            raise IllegalArgumentException("bitWidth must be >= 0 and <= 32")
+        self._bit_width = bitWidth
+        if stream is not None:
+            self.initFromPage(valueCount, stream)
+
+    readInt = ValuesReader.readInteger
+
+
+class ZeroIntegerValuesReader(ValuesReader):
+    """ZeroIntegerValuesReader.java:30-47: max level 0, consumes nothing, yields zeros."""
+
+    def initFromPage(self, valueCount, stream):
+        self._next_offset = 0
+
+    def readInteger(self):
+        return 0
+
+    def skip(self, n=1):
+        pass
+
+
+class DictionaryValuesReader(ValuesReader):
+    """DictionaryValuesReader.java:35-128; ``dictionary`` is the decoded PLAIN dictionary page as a
+    numpy array of int32/int64/float32/float64 (PlainValuesDictionary.java:148-157,232-241)."""
+    _encoding = ENC_RLE_DICTIONARY
+
+    def __init__(self, dictionary):
+        self._dict = _np.ascontiguousarray(dictionary)
+        self._dtype = self._dict.dtype
+        super().__init__()
+
+    def _dict_array(self):
+        return self._dict
+
+    def _fail_at_end(self):
+        if self._status == OK and len(self._values) == 0:
+            raise ParquetDecodingException("Attempt to read from empty page")
+        super()._fail_at_end()
+
+
+class DictionaryIdReader(ValuesReader):
+    """readValueDictionaryId() view of a dictionary-encoded page (DictionaryValuesReader.java:66-73)."""
+    _encoding = ENC_RLE
+    _flags = F_WIDTH_PREFIX
+
+
+class DeltaBinaryPackingValuesReader(ValuesReader):
+    """DeltaBinaryPackingValuesReader.java:33-173 (eager whole-page decode)."""
+    _encoding = ENC_DELTA_BINARY_PACKED
+
+    def __init__(self, dtype=_np.int64):
+        self._dtype = _np.dtype(dtype).type
+        super().__init__()
+
+    def initFromPage(self, valueCount, stream):
+        super().initFromPage(valueCount, stream)
+        if self._status != OK:
+            _raise_for(self._status)
+
+    def _consume(self, stream, r, start):
+        if r.status == OK:
+            stream.skipFully(r.bytes_consumed)
+            self._next_offset = r.bytes_consumed
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("no more value to read, total value count is %d" % len(self._values))
+
+    def skip(self, n=1):
+        if self._i + n > len(self._values):
+            self._fail_at_end()
+        self._i += n
+
+
+class ByteStreamSplitValuesReader(ValuesReader):
+    """ByteStreamSplitValuesReader.java:30-235 and its typed subclasses."""
+    _encoding = ENC_BYTE_STREAM_SPLIT
+
+    def __init__(self, dtype=None, length=None):
+        if dtype is None:
+            self._k = int(length)
+            self._dtype = _np.uint8
+        else:
+            self._dtype = _np.dtype(dtype).type
+            self._k = _np.dtype(dtype).itemsize
+        super().__init__()
+
+    def _elem_size(self):
+        return self._k
+
+    def initFromPage(self, valueCount, stream):
+        super().initFromPage(valueCount, stream)
+        if self._status != OK:
+            _raise_for(self._status, "Invalid ByteStreamSplit stream")
+
+    def _consume(self, stream, r, start):
+        if r.status == OK:
+            stream.skipFully(r.bytes_consumed)
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("Byte-stream data was already exhausted.")
+
+    def readBytes(self):
+        return bytes(self._next())
+
+    def skip(self, n=1):
+        if n < 0 or self._i + n > len(self._values):
+            raise ParquetDecodingException(
+                "Cannot skip this many elements. Current index: %d. Skip %d. Total number of elements: %d" %
+                (self._i, n, len(self._values)))
+        self._i += n
+
+
+class ByteBitPackingValuesReader(ValuesReader):
+    """ByteBitPackingValuesReader.java:29-94 with Packer.BIG_ENDIAN (legacy BIT_PACKED levels)."""
+    _encoding = ENC_BIT_PACKED
+
+    def __init__(self, bound):
+        super().__init__()
+        self._bit_width = int(bound).bit_length()  # BytesUtils.getWidthFromMaxInt
+
+    def _consume(self, stream, r, start):
+        stream.skipFully(r.bytes_consumed)
+        self._next_offset = r.bytes_consumed
+
+    def _fail_at_end(self):
+        raise IndexError("read past the page's value count")
+
+
+# ------------------------------------------------------------------------------- device-resident batches
+def make_descs(pages):
+    """Builds a host array of ``PageDesc`` from dicts with keys data/out/dict (device addresses as
+    ints), data_len, num_values, dict_len, encoding, elem_size, bit_width, flags."""
+    arr = (PageDesc * len(pages))()
+    for i, p in enumerate(pages):
+        d = arr[i]
+        d.data = p.get("data") or None
+        d.out = p.get("out") or None
+        d.dict = p.get("dict") or None
+        d.data_len = p.get("data_len", 0)
+        d.num_values = p.get("num_values", 0)
+        d.dict_len = p.get("dict_len", 0)
+        d.encoding = p["encoding"]
+        d.elem_size = p.get("elem_size", 4)
+        d.bit_width = p.get("bit_width", 0)
+        d.flags = p.get("flags", 0)
+    return arr
+
+
+def descs_to_numpy(arr):
+    return _np.frombuffer(bytes(arr), dtype=_np.uint8).copy()
+
+
+def results_from_numpy(raw):
+    r = _np.ascontiguousarray(raw).view(_np.uint32).reshape(-1, 4)
+    return r[:, 0].astype(_np.int32), r[:, 1].copy(), r[:, 2].copy()
+
+
+def decode_pages_dev(descs_dev_ptr, results_dev_ptr, n_pages, encoding, elem_size, stream=None):
+    """pqd_decode_pages_dev: descriptors and results already on the device; asynchronous on ``stream``."""
+    check(lib.pqd_decode_pages_dev(descs_dev_ptr, results_dev_ptr, n_pages, encoding, elem_size, stream),
+          "pqd_decode_pages_dev")

@@ -1,0 +1,88 @@
+"""ctypes binding of libpqdecode_hip.so (the C ABI declared in include/pqd.h).
+
+The library is the product: if it is missing this module raises at import, there is no CPU
+fallback.  torch is imported first so that the process holds a single HIP runtime (torch ships
+its own libamdhip64 with the same soname).
+"""
+import ctypes as C
+import os
+
+try:  # plumbing only: device memory, streams, torch.distributed
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpqdecode_hip.so")
+
+OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
+ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
+F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
+
+
+class PageDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("out", C.c_void_p), ("dict", C.c_void_p),
+                ("data_len", C.c_uint32), ("num_values", C.c_uint32), ("dict_len", C.c_uint32),
+                ("encoding", C.c_uint8), ("elem_size", C.c_uint8), ("bit_width", C.c_uint8), ("flags", C.c_uint8)]
+
+
+class PageResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("values_written", C.c_uint32), ("bytes_consumed", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+assert C.sizeof(PageDesc) == 40 and C.sizeof(PageResult) == 16
+
+EXPORTS = {
+    "pqd_version": ([], C.c_int),
+    "pqd_status_string": ([C.c_int], C.c_char_p),
+    "pqd_last_error": ([], C.c_char_p),
+    "pqd_device_count": ([], C.c_int),
+    "pqd_init": ([C.c_int], C.c_int),
+    "pqd_dev_alloc": ([C.POINTER(C.c_void_p), C.c_size_t], C.c_int),
+    "pqd_dev_free": ([C.c_void_p], C.c_int),
+    "pqd_host_alloc_pinned": ([C.POINTER(C.c_void_p), C.c_size_t], C.c_int),
+    "pqd_host_free_pinned": ([C.c_void_p], C.c_int),
+    "pqd_memcpy_h2d": ([C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
+    "pqd_memcpy_d2h": ([C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
+    "pqd_memset_dev": ([C.c_void_p, C.c_int, C.c_size_t, C.c_void_p], C.c_int),
+    "pqd_stream_create": ([C.POINTER(C.c_void_p)], C.c_int),
+    "pqd_stream_destroy": ([C.c_void_p], C.c_int),
+    "pqd_stream_sync": ([C.c_void_p], C.c_int),
+    "pqd_event_create": ([C.POINTER(C.c_void_p)], C.c_int),
+    "pqd_event_destroy": ([C.c_void_p], C.c_int),
+    "pqd_event_record": ([C.c_void_p, C.c_void_p], C.c_int),
+    "pqd_event_sync": ([C.c_void_p], C.c_int),
+    "pqd_event_elapsed_ms": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_float)], C.c_int),
+    "pqd_unpack_i32": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
+    "pqd_unpack_i32_dev": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
+    "pqd_unpack_i64": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
+    "pqd_unpack_i64_dev": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
+    "pqd_decode_pages_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "pqd_decode_pages": ([C.POINTER(PageDesc), C.POINTER(PageResult), C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_decode_page": ([C.POINTER(PageDesc), C.POINTER(PageResult)], C.c_int),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950). "
+        "There is no CPU fallback for the decode path.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_args, _res) in EXPORTS.items():
+    _fn = getattr(lib, _name)  # AttributeError if the library does not export a declared symbol
+    _fn.argtypes = _args
+    _fn.restype = _res
+
+
+class PqdError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib.pqd_status_string(status).decode()
+        detail = lib.pqd_last_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" [{detail}]" if detail else ""))
+
+
+def check(status, where=""):
+    if status != OK:
+        raise PqdError(status, where)

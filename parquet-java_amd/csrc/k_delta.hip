@@ -1,0 +1,347 @@
+// DELTA_BINARY_PACKED page decode -> int32 / int64.
+//
+// Replaces DeltaBinaryPackingValuesReader.initFromPage / loadNewBlockToBuffer / unpackMiniBlock
+// (parquet-column/.../values/delta/DeltaBinaryPackingValuesReader.java:60-172) and
+// DeltaBinaryPackingConfig.readConfig (DeltaBinaryPackingConfig.java:35-45).  The reference decodes
+// the whole page eagerly inside initFromPage; so does this kernel.
+//
+// One 256-thread workgroup per page:
+//   1. page bytes are staged into LDS window by window (coalesced 16-byte loads);
+//   2. lane 0 walks the block headers in the window (zig-zag min delta, one width byte per
+//      miniblock) and writes one table entry per miniblock {LDS byte offset, width, min delta};
+//   3. all lanes unpack: each lane owns four consecutive deltas, sums them with the block's min
+//      delta, and the page-wide running sum is formed with a wavefront scan (lane shuffles), a
+//      four-entry cross-wave table in LDS and a carry kept in registers from tile to tile.
+// Arithmetic wraps modulo 2^64 (2^32 for int32 output, which equals the reference's (int) cast of
+// the 64-bit sum).  HBM-bound: w/8 + 14/128 bytes in, 4 or 8 bytes out per value.
+#include <type_traits>
+
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+
+namespace pqd {
+
+constexpr int DELTA_THREADS = 256;
+constexpr int DWINDOW_BYTES = 24 * 1024;
+constexpr int DWINDOW_SLACK = 48;
+constexpr int DWINDOW_PIECES = (DWINDOW_BYTES + DWINDOW_SLACK) / 16;
+constexpr int MAX_MINIS = 1024;      // miniblock table entries per window
+constexpr int MAX_MINI_PER_BLOCK = 256;
+
+struct DeltaState {
+  uint32_t pos;           // next unread stream byte
+  uint32_t deltas_done;   // deltas expanded before the current window
+  uint32_t window_minis;  // table entries of the current window
+  uint32_t minis_left;    // miniblocks of the current block still to be emitted
+  uint32_t cur_mini;      // index of the next miniblock inside the current block
+  int32_t status;
+  uint32_t done;
+  int32_t window_base;
+  uint32_t block_size, mini_n, mini_size, total;
+  uint64_t first;
+  uint64_t min_delta;     // of the current block
+};
+
+__device__ __forceinline__ bool lds_varint(const uint32_t* win, int32_t base, uint32_t& p, uint32_t end,
+                                           uint64_t& out, bool is_long) {
+  uint64_t v = 0;
+  uint32_t shift = 0;
+  for (int i = 0; i < 12; ++i) {
+    if (p >= end) return false;
+    uint64_t b = lds_byte(win, p - base);
+    ++p;
+    uint32_t s = is_long ? (shift & 63u) : (shift & 31u);
+    if (b & 0x80u) {
+      v |= is_long ? ((b & 0x7Fu) << s) : (uint64_t)(uint32_t)((uint32_t)(b & 0x7Fu) << s);
+      shift += 7;
+    } else {
+      v |= is_long ? (b << s) : (uint64_t)(uint32_t)((uint32_t)b << s);
+      out = v;
+      return true;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ int64_t zigzag64(uint64_t raw) {  // BytesUtils.java:254-258
+  return (int64_t)((raw >> 1) ^ (~(raw & 1ull) + 1ull));
+}
+
+template <int ELEM>
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_desc* __restrict__ descs,
+                                                               pqd_page_result* __restrict__ results,
+                                                               uint32_t n_pages) {
+  typedef typename std::conditional<ELEM == 8, uint64_t, uint32_t>::type acc_t;
+  __shared__ u32x4 win4[DWINDOW_PIECES];
+  __shared__ uint32_t mini_src[MAX_MINIS];
+  __shared__ uint32_t mini_w[MAX_MINIS];
+  __shared__ uint64_t mini_min[MAX_MINIS];
+  __shared__ uint8_t cur_widths[MAX_MINI_PER_BLOCK];
+  __shared__ acc_t wave_sum[DELTA_THREADS / 64];
+  __shared__ DeltaState st;
+  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
+
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_page_desc d = descs[page];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t end = d.data_len;
+  const uint8_t* gend = d.data + end;
+
+  if (d.encoding != PQD_ENC_DELTA_BINARY_PACKED || d.elem_size != ELEM) {
+    if (tid == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+
+  // ---- page header: stage the first window, lane 0 parses it
+  {
+    const uint8_t* gbase = reinterpret_cast<const uint8_t*>((uintptr_t)d.data & ~(uintptr_t)15);
+    stage_window<DELTA_THREADS>(win4, gbase, gend, DWINDOW_PIECES);
+    __syncthreads();
+    if (tid == 0) {
+      const int32_t base = -(int32_t)(d.data - gbase);
+      uint32_t p = 0;
+      uint64_t block = 0, mini_n = 0, total = 0, first_raw = 0;
+      int32_t status = PQD_OK;
+      if (!lds_varint(win, base, p, end, block, false) || !lds_varint(win, base, p, end, mini_n, false)) {
+        status = PQD_EOF;
+      } else if ((int32_t)block < 0 || (int32_t)mini_n < 0) {
+        status = PQD_DECODE;
+      } else if (mini_n == 0 || block % mini_n != 0 || ((block / mini_n) & 7u) != 0) {
+        status = PQD_BAD_ARG;  // "miniBlockSize must be multiple of 8"
+      } else if (!lds_varint(win, base, p, end, total, false)) {
+        status = PQD_EOF;
+      } else if ((int32_t)total < 0 || total > d.num_values) {
+        status = PQD_DECODE;
+      } else if (!lds_varint(win, base, p, end, first_raw, true)) {
+        status = PQD_EOF;
+      } else if (total > 1 && (block == 0 || mini_n > MAX_MINI_PER_BLOCK)) {
+        status = PQD_DECODE;
+      }
+      st.pos = p;
+      st.deltas_done = 0;
+      st.window_minis = 0;
+      st.minis_left = 0;
+      st.cur_mini = 0;
+      st.status = status;
+      st.done = (status != PQD_OK || total <= 1) ? 1u : 0u;
+      st.window_base = base;
+      st.block_size = (uint32_t)block;
+      st.mini_n = (uint32_t)mini_n;
+      st.mini_size = mini_n ? (uint32_t)(block / mini_n) : 0u;
+      st.total = (uint32_t)total;
+      st.first = (uint64_t)zigzag64(first_raw);
+      st.min_delta = 0;
+    }
+    __syncthreads();
+  }
+
+  const uint32_t total = st.total;
+  const uint32_t mini_size = st.mini_size;
+  const uint32_t n_deltas = total > 0 ? total - 1 : 0;
+  acc_t carry = (acc_t)st.first;  // value at output index deltas_done
+  acc_t* out = reinterpret_cast<acc_t*>(d.out);
+  bool first_window = true;
+
+  while (st.done == 0) {
+    // ---- 1. stage (the header window is reused for the first pass)
+    const uint32_t cur = st.pos;
+    const uint8_t* gptr = d.data + cur;
+    const uint8_t* gbase = reinterpret_cast<const uint8_t*>((uintptr_t)gptr & ~(uintptr_t)15);
+    const int32_t wbase = (int32_t)cur - (int32_t)(gptr - gbase);
+    if (!first_window) {
+      __syncthreads();
+      stage_window<DELTA_THREADS>(win4, gbase, gend, DWINDOW_PIECES);
+      __syncthreads();
+    }
+    // ---- 2. block-header walk (loadNewBlockToBuffer, :121-143; readBitWidthsForMiniBlocks, :164-172)
+    if (tid == 0) {
+      const int32_t base = first_window ? st.window_base : wbase;
+      st.window_base = base;
+      const uint32_t wend = (uint32_t)(base + DWINDOW_BYTES);
+      uint32_t p = st.pos, nm = 0, left = st.minis_left, cm = st.cur_mini;
+      uint32_t scanned = st.deltas_done;
+      uint64_t min_delta = st.min_delta;
+      int32_t status = PQD_OK;
+      const uint32_t mini_bytes_unit = mini_size >> 3;
+      while (nm < MAX_MINIS && scanned < n_deltas) {
+        if (left == 0) {
+          if (nm > 0 && wend < end && p + 12 + st.mini_n > wend) break;  // header may straddle: restage
+          uint64_t raw;
+          if (!lds_varint(win, base, p, end, raw, true)) {
+            status = PQD_DECODE;  // "can not read min delta in current block"
+            break;
+          }
+          min_delta = (uint64_t)zigzag64(raw);
+          if (end - p < st.mini_n) {
+            status = PQD_DECODE;  // "Can not decode bitwidth in block header"
+            break;
+          }
+          for (uint32_t i = 0; i < st.mini_n; ++i) cur_widths[i] = (uint8_t)lds_byte(win, p - base + i);
+          p += st.mini_n;
+          const uint32_t need = (n_deltas - scanned + mini_size - 1) / mini_size;
+          left = need < st.mini_n ? need : st.mini_n;
+          cm = 0;
+        }
+        const uint32_t w = cur_widths[cm];
+        if (w > 64) {  // the packer table of the reference has 65 entries
+          status = PQD_DECODE;
+          break;
+        }
+        const uint32_t bytes = mini_bytes_unit * w;
+        if (end - p < bytes) {
+          status = PQD_EOF;  // in.slice(w) past the end
+          break;
+        }
+        if (p + bytes > wend) {
+          if (nm == 0) status = PQD_DECODE;  // a single miniblock larger than the staging window
+          break;
+        }
+        mini_src[nm] = (uint32_t)(p - base);
+        mini_w[nm] = w;
+        mini_min[nm] = min_delta;
+        ++nm;
+        p += bytes;
+        scanned += mini_size;
+        ++cm;
+        --left;
+      }
+      st.pos = p;
+      st.window_minis = nm;
+      st.minis_left = left;
+      st.cur_mini = cm;
+      st.min_delta = min_delta;
+      if (status != PQD_OK) {
+        st.status = status;
+        st.done = 1;
+      } else if (scanned >= n_deltas) {
+        st.done = 1;
+      }
+    }
+    __syncthreads();
+    first_window = false;
+    if (st.status != PQD_OK) break;
+
+    // ---- 3. unpack + running sum, 1024 deltas per tile
+    const uint32_t D0 = st.deltas_done;
+    const uint32_t wd = st.window_minis * mini_size;
+    for (uint32_t t0 = 0; t0 < wd; t0 += DELTA_THREADS * 4) {
+      const uint32_t l = t0 + tid * 4;
+      acc_t dv[4] = {0, 0, 0, 0};
+      acc_t mn = 0;
+      if (l < wd) {
+        const uint32_t m = l / mini_size;
+        const uint32_t w = mini_w[m];
+        mn = (acc_t)mini_min[m];
+        uint32_t bit = mini_src[m] * 8 + (l - m * mini_size) * w;
+        if (ELEM == 8) {
+          const uint64_t mask = mask64(w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t i = bit >> 5, sh = bit & 31u;
+            const uint32_t a = win[i], b = win[i + 1], c = win[i + 2];
+            const uint64_t v = ((uint64_t)funnel_shr(b, c, sh) << 32) | funnel_shr(a, b, sh);
+            dv[j] = (acc_t)(v & mask);
+            bit += w;
+          }
+        } else {
+          const uint32_t mask = mask32(w > 32 ? 32 : w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t i = bit >> 5, sh = bit & 31u;
+            dv[j] = (acc_t)(funnel_shr(win[i], win[i + 1], sh) & mask);
+            bit += w;
+          }
+        }
+      }
+      const acc_t s = (acc_t)(mn * 4 + dv[0] + dv[1] + dv[2] + dv[3]);
+      // inclusive scan over the wave
+      acc_t inc = s;
+      const uint32_t lane = tid & 63u;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        acc_t up;
+        if (ELEM == 8) {
+          uint32_t lo32 = __shfl_up((uint32_t)inc, off, 64);
+          uint32_t hi32 = __shfl_up((uint32_t)((uint64_t)inc >> 32), off, 64);
+          up = (acc_t)(((uint64_t)hi32 << 32) | lo32);
+        } else {
+          up = (acc_t)__shfl_up((uint32_t)inc, off, 64);
+        }
+        if (lane >= (uint32_t)off) inc += up;
+      }
+      if (lane == 63) wave_sum[tid >> 6] = inc;
+      __syncthreads();
+      acc_t before = 0, tile_total = 0;
+#pragma unroll
+      for (int k = 0; k < DELTA_THREADS / 64; ++k) {
+        const acc_t ws = wave_sum[k];
+        if ((uint32_t)k < (tid >> 6)) before += ws;
+        tile_total += ws;
+      }
+      const acc_t o0 = (acc_t)(carry + before + inc - s);
+      if (l < wd) {
+        const acc_t o1 = (acc_t)(o0 + mn + dv[0]);
+        const acc_t o2 = (acc_t)(o1 + mn + dv[1]);
+        const acc_t o3 = (acc_t)(o2 + mn + dv[2]);
+        const uint32_t g0 = D0 + l;
+        if (g0 + 4 <= total) {
+          if (ELEM == 8) {
+            u32x4_a4 r0 = {(uint32_t)o0, (uint32_t)((uint64_t)o0 >> 32), (uint32_t)o1, (uint32_t)((uint64_t)o1 >> 32)};
+            u32x4_a4 r1 = {(uint32_t)o2, (uint32_t)((uint64_t)o2 >> 32), (uint32_t)o3, (uint32_t)((uint64_t)o3 >> 32)};
+            *reinterpret_cast<u32x4_a4*>(out + g0) = r0;
+            *reinterpret_cast<u32x4_a4*>(out + g0 + 2) = r1;
+          } else {
+            u32x4_a4 r = {(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)o3};
+            *reinterpret_cast<u32x4_a4*>(out + g0) = r;
+          }
+        } else {
+          if (g0 < total) out[g0] = o0;
+          if (g0 + 1 < total) out[g0 + 1] = o1;
+          if (g0 + 2 < total) out[g0 + 2] = o2;
+          if (g0 + 3 < total) out[g0 + 3] = o3;
+        }
+      }
+      carry = (acc_t)(carry + tile_total);
+      __syncthreads();  // wave_sum is reused by the next tile
+    }
+    if (tid == 0) st.deltas_done = D0 + wd;
+    __syncthreads();
+  }
+
+  if (tid == 0) {
+    pqd_page_result r;
+    r.status = st.status;
+    r.reserved = 0;
+    if (st.status == PQD_OK) {
+      // the value that follows the last unpacked delta (also the lone header value of a 1-value page)
+      if (st.deltas_done < total) out[st.deltas_done] = carry;
+      r.values_written = total;
+      r.bytes_consumed = st.pos;
+    } else {
+      r.values_written = 0;
+      r.bytes_consumed = 0;
+    }
+    results[page] = r;
+  }
+}
+
+template __global__ void k_delta_pages<4>(const pqd_page_desc*, pqd_page_result*, uint32_t);
+template __global__ void k_delta_pages<8>(const pqd_page_desc*, pqd_page_result*, uint32_t);
+
+
+hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
+                              hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  const dim3 grid(n_pages), block(DELTA_THREADS);
+  if (elem == 4)
+    hipLaunchKernelGGL((k_delta_pages<4>), grid, block, 0, stream, descs, results, n_pages);
+  else
+    hipLaunchKernelGGL((k_delta_pages<8>), grid, block, 0, stream, descs, results, n_pages);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -1,0 +1,439 @@
+// RLE / bit-packing hybrid page decode, optionally fused with the dictionary gather.
+//
+// Replaces RunLengthBitPackingHybridDecoder.readInt/readNext
+// (parquet-column/.../values/rle/RunLengthBitPackingHybridDecoder.java:52-109), its wrappers
+// RunLengthBitPackingHybridValuesReader (:41-66, 4-byte length prefix) and DictionaryValuesReader
+// (parquet-column/.../values/dictionary/DictionaryValuesReader.java:49-127, 1-byte width prefix,
+// value = dictionary[id]).
+//
+// One 256-thread workgroup decodes one page:
+//   1. the page bytes are staged into LDS, a window of WINDOW_BYTES at a time, with coalesced
+//      16-byte loads (bytes past the end of the stream are staged as zero: a truncated final
+//      bit-packed run decodes zeros, as in the Java);
+//   2. lane 0 walks the run headers inside the window (varint header, then either the RLE value or
+//      groups*w payload bytes) and writes a segment table {first output index, source} to LDS;
+//   3. all lanes expand: each lane owns four consecutive output values per step, finds their
+//      segment by binary search, extracts the ids from the LDS window with funnel shifts (or
+//      broadcasts the RLE value), gathers dictionary[id] and stores 16 or 32 contiguous bytes.
+// HBM-bound: w/8 bytes in + elem bytes out per value; the dictionary is read through L2.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+
+namespace pqd {
+
+constexpr int RLE_THREADS = 256;
+constexpr int WINDOW_BYTES = 24 * 1024;
+constexpr int WINDOW_SLACK = 48;  // >= 15 (alignment) + 20 (window over-read) rounded up
+constexpr int WINDOW_PIECES = (WINDOW_BYTES + WINDOW_SLACK) / 16;
+constexpr int MAX_SEGS = 512;
+constexpr uint32_t SEG_RLE = 0u, SEG_PACKED = 1u;
+
+struct RleState {
+  uint32_t pos;             // next unread byte of the stream (offset from desc.data)
+  uint32_t produced;        // values expanded before the current window
+  uint32_t window_values;   // values covered by the current segment table
+  uint32_t nseg;
+  uint32_t pending_groups;  // groups left of a bit-packed run whose header is already consumed
+  int32_t scan_status;      // first failure met by the header walk, PQD_OK if none
+  uint32_t scan_err_at;     // output index at which that failure happens
+  uint32_t oob_at;          // smallest output index with id >= dict_len (atomicMin), ~0u if none
+  uint32_t done;
+  int32_t window_base;      // stream offset of LDS byte 0 (may be slightly negative)
+};
+
+template <int ELEM, bool HAS_DICT>
+__device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint32_t lo, uint32_t hi,
+                                      const uint32_t id[4], uint32_t* oob_at) {
+  // g0 = global output index of id[0]; only indices in [lo, hi) are written
+  if (HAS_DICT) {
+    const uint32_t dict_len = d.dict_len;
+    uint32_t bad = ~0u;
+#pragma unroll
+    for (int j = 3; j >= 0; --j)
+      if (g0 + j >= lo && g0 + j < hi && id[j] >= dict_len) bad = g0 + j;
+    if (bad != ~0u) atomicMin(oob_at, bad);
+    if (ELEM == 4) {
+      const uint32_t* dict = reinterpret_cast<const uint32_t*>(d.dict);
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = id[j] < dict_len ? dict[id[j]] : 0u;
+      uint32_t* o = reinterpret_cast<uint32_t*>(d.out) + g0;
+      if (g0 >= lo && g0 + 4 <= hi) {
+        u32x4_a4 r = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<u32x4_a4*>(o) = r;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (g0 + j >= lo && g0 + j < hi) o[j] = v[j];
+      }
+    } else {
+      const u32x2_a4* dict = reinterpret_cast<const u32x2_a4*>(d.dict);
+      u32x2_a4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x2_a4 z = {0u, 0u};
+        v[j] = id[j] < dict_len ? dict[id[j]] : z;
+      }
+      u32x2_a4* o = reinterpret_cast<u32x2_a4*>(d.out) + g0;
+      if (g0 >= lo && g0 + 4 <= hi) {
+        u32x4_a4 r0 = {v[0].x, v[0].y, v[1].x, v[1].y};
+        u32x4_a4 r1 = {v[2].x, v[2].y, v[3].x, v[3].y};
+        *reinterpret_cast<u32x4_a4*>(o) = r0;
+        *reinterpret_cast<u32x4_a4*>(o + 2) = r1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (g0 + j >= lo && g0 + j < hi) o[j] = v[j];
+      }
+    }
+  } else {
+    uint32_t* o = reinterpret_cast<uint32_t*>(d.out) + g0;
+    if (g0 >= lo && g0 + 4 <= hi) {
+      u32x4_a4 r = {id[0], id[1], id[2], id[3]};
+      *reinterpret_cast<u32x4_a4*>(o) = r;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (g0 + j >= lo && g0 + j < hi) o[j] = id[j];
+    }
+  }
+}
+
+// Header walk over the staged window; run by one lane.  Follows readNext() (:80-109).
+__device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg_start, uint32_t* seg_src,
+                                uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values) {
+  uint32_t pos = st.pos;
+  const int32_t base = st.window_base;
+  const uint32_t wend = (uint32_t)(base + WINDOW_BYTES);  // stream offset one past the window
+  const uint32_t remaining = n_values - st.produced;
+  uint32_t vals = 0, nseg = 0, pending = st.pending_groups;
+  int32_t status = PQD_OK;
+  bool stop = false;
+  while (!stop && nseg < MAX_SEGS && vals < remaining) {
+    if (pending == 0) {
+      if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
+        status = PQD_PAST_END;
+        break;
+      }
+      if (nseg > 0 && pos + 16 > wend && wend < end) break;  // header may straddle the window: restage
+      // BytesUtils.readUnsignedVarInt (parquet-common/.../BytesUtils.java:202-211)
+      uint32_t header = 0, shift = 0, p = pos, nb = 0;
+      for (;;) {
+        if (p >= end) {
+          status = PQD_EOF;
+          break;
+        }
+        if (++nb > 10) {  // over-long varint: not produced by any writer
+          status = PQD_DECODE;
+          break;
+        }
+        uint32_t b = lds_byte(win, p - base);
+        ++p;
+        if (b & 0x80u) {
+          header |= (b & 0x7Fu) << (shift & 31u);
+          shift += 7;
+        } else {
+          header |= b << (shift & 31u);
+          break;
+        }
+      }
+      if (status) break;
+      if ((header & 1u) == 0) {
+        // RLE run: value on ceil(w/8) little-endian bytes, not masked to w (BytesUtils.java:124-142)
+        uint32_t count = header >> 1;
+        uint32_t nbytes = (w + 7) >> 3;
+        if (end - p < nbytes) {
+          status = PQD_EOF;
+          break;
+        }
+        uint32_t value = 0;
+        for (uint32_t i = 0; i < nbytes; ++i) value |= lds_byte(win, p - base + i) << (8 * i);
+        p += nbytes;
+        pos = p;
+        // a zero-count run leaves currentCount negative: the value repeats for the rest of the page
+        uint32_t take = (count == 0 || count > remaining - vals) ? remaining - vals : count;
+        seg_start[nseg] = vals;
+        seg_src[nseg] = value;
+        seg_kind[nseg] = SEG_RLE;
+        ++nseg;
+        vals += take;
+        continue;
+      }
+      uint32_t groups = header >> 1;
+      if (groups == 0 || groups > 0x0FFFFFFFu) {  // empty buffer indexed / negative array size
+        status = PQD_DECODE;
+        break;
+      }
+      pending = groups;
+      pos = p;
+    }
+    // bit-packed groups (8 values, w bytes each)
+    const uint32_t want_groups = (remaining - vals + 7) >> 3;
+    if (w == 0) {
+      uint32_t g = pending < want_groups ? pending : want_groups;
+      uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
+      seg_start[nseg] = vals;
+      seg_src[nseg] = 0;
+      seg_kind[nseg] = SEG_RLE;
+      ++nseg;
+      vals += take;
+      pending = 0;
+      continue;
+    }
+    const uint32_t avail = end > pos ? end - pos : 0u;      // real bytes left in the stream
+    const uint32_t with_data = (avail + w - 1) / w;         // groups holding at least one real byte
+    const uint32_t in_window = wend > pos ? (wend - pos) / w : 0u;
+    uint32_t g = pending;
+    if (g > want_groups) g = want_groups;
+    if (with_data == 0) {
+      // the stream ended inside the run: the rest of its buffer stays zero (:95-99)
+      uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
+      seg_start[nseg] = vals;
+      seg_src[nseg] = 0;
+      seg_kind[nseg] = SEG_RLE;
+      ++nseg;
+      vals += take;
+      pending = 0;
+      continue;
+    }
+    if (g > with_data) g = with_data;
+    if (g > in_window) g = in_window;
+    if (g == 0) {
+      stop = true;  // window exhausted: restage from pos
+      break;
+    }
+    uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
+    seg_start[nseg] = vals;
+    seg_src[nseg] = (uint32_t)(pos - base);  // LDS byte offset of the first group
+    seg_kind[nseg] = SEG_PACKED;
+    ++nseg;
+    vals += take;
+    uint32_t bytes = g * w;
+    pos += bytes > avail ? avail : bytes;
+    pending -= g;
+  }
+  seg_start[nseg] = vals;
+  st.nseg = nseg;
+  st.window_values = vals;
+  st.pending_groups = pending;
+  if (status != PQD_OK) {
+    st.scan_status = status;
+    st.scan_err_at = st.produced + vals;
+    st.done = 1;
+  } else if (st.produced + vals >= n_values) {
+    // readNext consumed the whole payload of the last run when its header was read
+    if (pending > 0 && w > 0) {
+      uint64_t rest = (uint64_t)pending * w;
+      uint32_t avail = end > pos ? end - pos : 0u;
+      pos += rest > avail ? avail : (uint32_t)rest;
+    }
+    st.done = 1;
+  }
+  st.pos = pos;
+}
+
+template <int ELEM, bool HAS_DICT>
+__global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
+                                                           pqd_page_result* __restrict__ results,
+                                                           uint32_t n_pages) {
+  __shared__ u32x4 win4[WINDOW_PIECES];
+  __shared__ uint32_t seg_start[MAX_SEGS + 1];
+  __shared__ uint32_t seg_src[MAX_SEGS];
+  __shared__ uint32_t seg_kind[MAX_SEGS];
+  __shared__ RleState st;
+  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
+
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_page_desc d = descs[page];
+  const uint32_t tid = threadIdx.x;
+
+  // ---- validation and stream prefixes (uniform over the workgroup)
+  int32_t early = PQD_OK;
+  bool finished = false;
+  uint32_t pos = 0, end = d.data_len, w = d.bit_width, consumed_override = ~0u;
+  const uint32_t n_values = d.num_values;
+  const bool is_dict = d.encoding == PQD_ENC_RLE_DICTIONARY;
+  if ((d.encoding != PQD_ENC_RLE && !is_dict) || is_dict != HAS_DICT || (HAS_DICT && d.elem_size != ELEM) ||
+      (!HAS_DICT && d.elem_size != 4)) {
+    early = PQD_BAD_ARG;
+    finished = true;
+  } else if (is_dict || (d.flags & PQD_F_WIDTH_PREFIX)) {
+    if (end == 0) {  // DictionaryValuesReader.java:56-63: an empty page fails on the first read only
+      early = n_values ? PQD_DECODE : PQD_OK;
+      finished = true;
+    } else {
+      w = d.data[0];
+      pos = 1;
+    }
+  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
+    if (end < 4) {
+      early = PQD_EOF;
+      finished = true;
+    } else {
+      uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) |
+                     ((uint32_t)d.data[3] << 24);
+      if ((int32_t)len < 0) {
+        early = PQD_DECODE;
+        finished = true;
+      } else if (len > end - 4) {
+        early = PQD_EOF;
+        finished = true;
+      } else {
+        pos = 4;
+        end = 4 + len;
+        consumed_override = end;
+      }
+    }
+  }
+  if (!finished && w > 32) {  // RunLengthBitPackingHybridDecoder.java:55
+    early = PQD_BAD_ARG;
+    finished = true;
+  }
+  if (finished || n_values == 0) {
+    if (tid == 0) {
+      pqd_page_result r;
+      r.status = early;
+      r.values_written = 0;
+      r.bytes_consumed = early == PQD_OK ? (consumed_override != ~0u ? consumed_override : pos) : 0;
+      r.reserved = 0;
+      results[page] = r;
+    }
+    return;
+  }
+
+  if (tid == 0) {
+    st.pos = pos;
+    st.produced = 0;
+    st.window_values = 0;
+    st.nseg = 0;
+    st.pending_groups = 0;
+    st.scan_status = PQD_OK;
+    st.scan_err_at = ~0u;
+    st.oob_at = ~0u;
+    st.done = 0;
+    st.window_base = 0;
+  }
+  __syncthreads();
+
+  const uint8_t* gend = d.data + end;
+  const uint32_t mask = mask32(w);
+  for (;;) {
+    // ---- 1. stage the window that starts at the 16-byte block holding st.pos
+    const uint32_t cur = st.pos;
+    const uint8_t* gptr = d.data + cur;
+    const uint8_t* gbase = reinterpret_cast<const uint8_t*>((uintptr_t)gptr & ~(uintptr_t)15);
+    const int32_t wbase = (int32_t)cur - (int32_t)(gptr - gbase);
+    stage_window<RLE_THREADS>(win4, gbase, gend, WINDOW_PIECES);
+    __syncthreads();
+    // ---- 2. header walk
+    if (tid == 0) {
+      st.window_base = wbase;
+      rle_scan_window(st, win, seg_start, seg_src, seg_kind, w, end, n_values);
+    }
+    __syncthreads();
+    // ---- 3. expansion
+    const uint32_t produced = st.produced;
+    const uint32_t wv = st.window_values;
+    const uint32_t nseg = st.nseg;
+    const uint32_t lo = produced, hi = produced + wv;
+    if (wv > 0) {
+      const uint32_t first_unit = lo >> 2, last_unit = (hi + 3) >> 2;
+      uint32_t s = 0;  // segment cursor (units only move forward)
+      for (uint32_t u = first_unit + tid; u < last_unit; u += RLE_THREADS) {
+        const uint32_t g0 = u << 2;
+        // local index of the first value of this unit that lies in the window
+        const uint32_t l0 = (g0 > lo ? g0 : lo) - lo;
+        // last segment with seg_start <= l0
+        uint32_t a = s, b = nseg;  // invariant: seg_start[a] <= l0 < seg_start[b]
+        while (b - a > 1) {
+          uint32_t m = (a + b) >> 1;
+          if (seg_start[m] <= l0)
+            a = m;
+          else
+            b = m;
+        }
+        s = a;
+        uint32_t id[4];
+        const uint32_t s_begin = seg_start[s], s_end = seg_start[s + 1];
+        if (g0 >= lo && g0 + 4 <= hi && (g0 - lo) + 4 <= s_end) {
+          // whole unit inside one segment
+          const uint32_t src = seg_src[s];
+          if (seg_kind[s] == SEG_PACKED) {
+            Window5 wnd = load_window(win, src * 8 + (g0 - lo - s_begin) * w);
+            id[0] = wnd.d0 & mask;
+            wnd.drop(w);
+            id[1] = wnd.d0 & mask;
+            wnd.drop(w);
+            id[2] = wnd.d0 & mask;
+            wnd.drop(w);
+            id[3] = wnd.d0 & mask;
+          } else {
+            id[0] = id[1] = id[2] = id[3] = src;
+          }
+        } else {
+          // unit straddles segments or the window edge: value by value
+          uint32_t t = s;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            id[j] = 0;
+            const uint32_t g = g0 + j;
+            if (g < lo || g >= hi) continue;
+            const uint32_t l = g - lo;
+            while (seg_start[t + 1] <= l) ++t;
+            const uint32_t src = seg_src[t];
+            if (seg_kind[t] == SEG_PACKED) {
+              const uint32_t bit = src * 8 + (l - seg_start[t]) * w;
+              const uint32_t i = bit >> 5;
+              id[j] = funnel_shr(win[i], win[i + 1], bit & 31u) & mask;
+            } else {
+              id[j] = src;
+            }
+          }
+        }
+        emit4<ELEM, HAS_DICT>(d, g0, lo, hi, id, &st.oob_at);
+      }
+    }
+    __syncthreads();
+    const bool done = st.done != 0;
+    if (tid == 0) st.produced = produced + wv;
+    if (done) break;
+    __syncthreads();
+  }
+
+  if (tid == 0) {
+    pqd_page_result r;
+    uint32_t limit = st.scan_status != PQD_OK ? st.scan_err_at : n_values;
+    if (limit > n_values) limit = n_values;
+    if (HAS_DICT && st.oob_at < limit) {
+      r.status = PQD_DICT_OOB;
+      r.values_written = st.oob_at;
+    } else {
+      r.status = st.scan_status;
+      r.values_written = limit;
+    }
+    r.bytes_consumed = consumed_override != ~0u ? consumed_override : st.pos;
+    r.reserved = 0;
+    results[page] = r;
+  }
+}
+
+template __global__ void k_rle_pages<4, false>(const pqd_page_desc*, pqd_page_result*, uint32_t);
+template __global__ void k_rle_pages<4, true>(const pqd_page_desc*, pqd_page_result*, uint32_t);
+template __global__ void k_rle_pages<8, true>(const pqd_page_desc*, pqd_page_result*, uint32_t);
+
+
+hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
+                            bool has_dict, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  const dim3 grid(n_pages), block(RLE_THREADS);
+  if (!has_dict)
+    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages);
+  else if (elem == 4)
+    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages);
+  else
+    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -1,0 +1,360 @@
+// C ABI of libpqdecode_hip.so (see include/pqd.h): argument checks, dispatch to the kernels, and
+// the host-memory convenience paths (stage -> decode -> copy back).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pqd.h"
+#include "pqd_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess)
+    snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+  else
+    snprintf(buf, sizeof buf, "%s", what);
+  g_last_error = buf;
+  return status;
+}
+
+#define PQD_HIP(expr)                                            \
+  do {                                                           \
+    hipError_t e_ = (expr);                                      \
+    if (e_ != hipSuccess) return fail(PQD_HIP_ERROR, #expr, e_); \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Growable device buffer owned by one host thread (used only by the host-memory entry points).
+struct Scratch {
+  void* p = nullptr;
+  size_t cap = 0;
+  int device = -1;
+  int ensure(size_t bytes) {
+    int dev = 0;
+    PQD_HIP(hipGetDevice(&dev));
+    if (p && device == dev && cap >= bytes) return PQD_OK;
+    if (p) {
+      (void)hipFree(p);
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+    PQD_HIP(hipMalloc(&p, want));
+    cap = want;
+    device = dev;
+    return PQD_OK;
+  }
+};
+
+struct HostCtx {
+  Scratch in, out, dict, descs, results;
+};
+thread_local HostCtx g_ctx;
+
+int check_device_available() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(PQD_NO_DEVICE, "no HIP device visible");
+  return PQD_OK;
+}
+
+int class_of(const pqd_page_desc& d) {  // pages that can share a launch
+  return ((int)d.encoding << 8) | (int)(d.encoding == PQD_ENC_BYTE_STREAM_SPLIT ? 0 : d.elem_size);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pqd_version(void) { return PQD_VERSION; }
+
+const char* pqd_status_string(int status) {
+  switch (status) {
+    case PQD_OK: return "ok";
+    case PQD_EOF: return "EOFException: stream shorter than the decode needs";
+    case PQD_BAD_ARG: return "IllegalArgumentException: argument outside the contract";
+    case PQD_PAST_END: return "IllegalArgumentException: Reading past RLE/BitPacking stream.";
+    case PQD_DECODE: return "ParquetDecodingException: malformed page";
+    case PQD_DICT_OOB: return "ParquetDecodingException: dictionary id out of range";
+    case PQD_HIP_ERROR: return "HIP runtime error";
+    case PQD_NO_DEVICE: return "no usable gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+const char* pqd_last_error(void) { return g_last_error.c_str(); }
+
+int pqd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  int usable = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+  }
+  return usable;
+}
+
+int pqd_init(int device) {
+  int st = check_device_available();
+  if (st) return st;
+  hipDeviceProp_t prop;
+  PQD_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(PQD_NO_DEVICE, "device is not gfx950");
+  PQD_HIP(hipSetDevice(device));
+  return PQD_OK;
+}
+
+int pqd_dev_alloc(void** p, size_t bytes) {
+  if (!p) return fail(PQD_BAD_ARG, "pqd_dev_alloc: null out pointer");
+  PQD_HIP(hipMalloc(p, bytes ? bytes : 1));
+  return PQD_OK;
+}
+int pqd_dev_free(void* p) {
+  if (p) PQD_HIP(hipFree(p));
+  return PQD_OK;
+}
+int pqd_host_alloc_pinned(void** p, size_t bytes) {
+  if (!p) return fail(PQD_BAD_ARG, "pqd_host_alloc_pinned: null out pointer");
+  PQD_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return PQD_OK;
+}
+int pqd_host_free_pinned(void* p) {
+  if (p) PQD_HIP(hipHostFree(p));
+  return PQD_OK;
+}
+int pqd_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes) PQD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes) PQD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_memset_dev(void* dst, int value, size_t bytes, void* stream) {
+  if (bytes) PQD_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_stream_create(void** stream) {
+  if (!stream) return fail(PQD_BAD_ARG, "pqd_stream_create: null out pointer");
+  hipStream_t s;
+  PQD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return PQD_OK;
+}
+int pqd_stream_destroy(void* stream) {
+  if (stream) PQD_HIP(hipStreamDestroy(as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_stream_sync(void* stream) {
+  PQD_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_event_create(void** ev) {
+  if (!ev) return fail(PQD_BAD_ARG, "pqd_event_create: null out pointer");
+  hipEvent_t e;
+  PQD_HIP(hipEventCreate(&e));
+  *ev = e;
+  return PQD_OK;
+}
+int pqd_event_destroy(void* ev) {
+  if (ev) PQD_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)));
+  return PQD_OK;
+}
+int pqd_event_record(void* ev, void* stream) {
+  PQD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), as_stream(stream)));
+  return PQD_OK;
+}
+int pqd_event_sync(void* ev) {
+  PQD_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
+  return PQD_OK;
+}
+int pqd_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!ms) return fail(PQD_BAD_ARG, "pqd_event_elapsed_ms: null out pointer");
+  PQD_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return PQD_OK;
+}
+
+/* ---- bulk bit-unpack ----------------------------------------------------------------------- */
+
+static int check_unpack_args(int bit_width, int max_width, const void* in, size_t in_len, const void* out,
+                             size_t n_values, size_t* total) {
+  if (bit_width < 0 || bit_width > max_width) return fail(PQD_BAD_ARG, "bit width out of range");
+  if (n_values & 7) return fail(PQD_BAD_ARG, "value count must be a multiple of 8");
+  *total = n_values / 8 * (size_t)bit_width;
+  if (in_len < *total) return fail(PQD_EOF, "bit-packed run shorter than n_values*bit_width/8 bytes");
+  if (n_values && !out) return fail(PQD_BAD_ARG, "null output");
+  if (*total && !in) return fail(PQD_BAD_ARG, "null input");
+  return PQD_OK;
+}
+
+int pqd_unpack_i32_dev(int bit_width, const uint8_t* in, size_t in_len, int32_t* out, size_t n_values,
+                       void* stream) {
+  size_t total;
+  int st = check_unpack_args(bit_width, 32, in, in_len, out, n_values, &total);
+  if (st) return st;
+  if (n_values == 0) return PQD_OK;
+  if (bit_width == 0) {  // the Java unpack writes nothing; a fresh int[] holds zeros
+    PQD_HIP(hipMemsetAsync(out, 0, n_values * sizeof(int32_t), as_stream(stream)));
+    return PQD_OK;
+  }
+  PQD_HIP(pqd::launch_unpack_run_i32(in, total, out, n_values, (uint32_t)bit_width, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_unpack_i64_dev(int bit_width, const uint8_t* in, size_t in_len, int64_t* out, size_t n_values,
+                       void* stream) {
+  size_t total;
+  int st = check_unpack_args(bit_width, 64, in, in_len, out, n_values, &total);
+  if (st) return st;
+  if (n_values == 0) return PQD_OK;
+  if (bit_width == 0) {
+    PQD_HIP(hipMemsetAsync(out, 0, n_values * sizeof(int64_t), as_stream(stream)));
+    return PQD_OK;
+  }
+  PQD_HIP(pqd::launch_unpack_run_i64(in, total, out, n_values, (uint32_t)bit_width, as_stream(stream)));
+  return PQD_OK;
+}
+
+static int unpack_host(int bit_width, int elem, const uint8_t* in, size_t in_len, void* out, size_t n_values) {
+  size_t total;
+  int st = check_unpack_args(bit_width, elem == 4 ? 32 : 64, in, in_len, out, n_values, &total);
+  if (st) return st;
+  if (n_values == 0) return PQD_OK;
+  if ((st = check_device_available())) return st;
+  HostCtx& c = g_ctx;
+  if ((st = c.in.ensure(total + 16))) return st;
+  if ((st = c.out.ensure(n_values * (size_t)elem))) return st;
+  if (total) PQD_HIP(hipMemcpyAsync(c.in.p, in, total, hipMemcpyHostToDevice, nullptr));
+  if (elem == 4)
+    st = pqd_unpack_i32_dev(bit_width, (const uint8_t*)c.in.p, total, (int32_t*)c.out.p, n_values, nullptr);
+  else
+    st = pqd_unpack_i64_dev(bit_width, (const uint8_t*)c.in.p, total, (int64_t*)c.out.p, n_values, nullptr);
+  if (st) return st;
+  PQD_HIP(hipMemcpyAsync(out, c.out.p, n_values * (size_t)elem, hipMemcpyDeviceToHost, nullptr));
+  PQD_HIP(hipStreamSynchronize(nullptr));
+  return PQD_OK;
+}
+
+int pqd_unpack_i32(int bit_width, const uint8_t* in, size_t in_len, int32_t* out, size_t n_values) {
+  return unpack_host(bit_width, 4, in, in_len, out, n_values);
+}
+int pqd_unpack_i64(int bit_width, const uint8_t* in, size_t in_len, int64_t* out, size_t n_values) {
+  return unpack_host(bit_width, 8, in, in_len, out, n_values);
+}
+
+/* ---- page decode ---------------------------------------------------------------------------- */
+
+int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,
+                         int elem_size, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  hipStream_t s = as_stream(stream);
+  switch (encoding) {
+    case PQD_ENC_RLE:
+      if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_RLE produces 4-byte values");
+      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, s));
+      return PQD_OK;
+    case PQD_ENC_RLE_DICTIONARY:
+      if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");
+      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, s));
+      return PQD_OK;
+    case PQD_ENC_DELTA_BINARY_PACKED:
+      if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "delta values must be 4 or 8 bytes");
+      PQD_HIP(pqd::launch_delta_pages(descs, results, n_pages, elem_size, s));
+      return PQD_OK;
+    case PQD_ENC_BYTE_STREAM_SPLIT:
+      PQD_HIP(pqd::launch_bss_pages(descs, results, n_pages, s));
+      return PQD_OK;
+    case PQD_ENC_BIT_PACKED:
+      if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_BIT_PACKED produces 4-byte values");
+      PQD_HIP(pqd::launch_bitpacked_pages(descs, results, n_pages, s));
+      return PQD_OK;
+    default:
+      return fail(PQD_BAD_ARG, "unknown encoding");
+  }
+}
+
+int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  int st = check_device_available();
+  if (st) return st;
+  hipStream_t s = as_stream(stream);
+  HostCtx& c = g_ctx;
+  if ((st = c.descs.ensure((size_t)n_pages * sizeof(pqd_page_desc)))) return st;
+  if ((st = c.results.ensure((size_t)n_pages * sizeof(pqd_page_result)))) return st;
+  // order the pages by launch class, remembering where each came from
+  std::vector<uint32_t> order(n_pages);
+  for (uint32_t i = 0; i < n_pages; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](uint32_t a, uint32_t b) { return class_of(descs[a]) < class_of(descs[b]); });
+  std::vector<pqd_page_desc> sorted(n_pages);
+  for (uint32_t i = 0; i < n_pages; ++i) sorted[i] = descs[order[i]];
+  PQD_HIP(hipMemcpyAsync(c.descs.p, sorted.data(), (size_t)n_pages * sizeof(pqd_page_desc), hipMemcpyHostToDevice, s));
+  pqd_page_desc* d_descs = (pqd_page_desc*)c.descs.p;
+  pqd_page_result* d_results = (pqd_page_result*)c.results.p;
+  for (uint32_t a = 0; a < n_pages;) {
+    uint32_t b = a + 1;
+    while (b < n_pages && class_of(sorted[b]) == class_of(sorted[a])) ++b;
+    st = pqd_decode_pages_dev(d_descs + a, d_results + a, b - a, sorted[a].encoding, sorted[a].elem_size, s);
+    if (st == PQD_BAD_ARG) {
+      // an encoding class the library does not know: report it per page, keep decoding the others
+      std::vector<pqd_page_result> bad(b - a, pqd_page_result{PQD_BAD_ARG, 0u, 0u, 0u});
+      PQD_HIP(hipMemcpyAsync(d_results + a, bad.data(), bad.size() * sizeof(pqd_page_result),
+                             hipMemcpyHostToDevice, s));
+      PQD_HIP(hipStreamSynchronize(s));
+    } else if (st) {
+      return st;
+    }
+    a = b;
+  }
+  std::vector<pqd_page_result> tmp(n_pages);
+  PQD_HIP(hipMemcpyAsync(tmp.data(), d_results, (size_t)n_pages * sizeof(pqd_page_result), hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < n_pages; ++i) results[order[i]] = tmp[i];
+  return PQD_OK;
+}
+
+int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result) {
+  if (!desc || !result) return fail(PQD_BAD_ARG, "null descriptor / result");
+  int st = check_device_available();
+  if (st) return st;
+  HostCtx& c = g_ctx;
+  pqd_page_desc d = *desc;
+  const size_t out_bytes = (size_t)d.num_values * (d.elem_size ? d.elem_size : 1);
+  if (d.data_len && !d.data) return fail(PQD_BAD_ARG, "null page data");
+  if (out_bytes && !d.out) return fail(PQD_BAD_ARG, "null output");
+  if ((st = c.in.ensure((size_t)d.data_len + 16))) return st;
+  if ((st = c.out.ensure(out_bytes + 16))) return st;
+  if (d.data_len) PQD_HIP(hipMemcpyAsync(c.in.p, d.data, d.data_len, hipMemcpyHostToDevice, nullptr));
+  d.data = (const uint8_t*)c.in.p;
+  void* host_out = d.out;
+  d.out = c.out.p;
+  if (d.encoding == PQD_ENC_RLE_DICTIONARY) {
+    const size_t dict_bytes = (size_t)d.dict_len * d.elem_size;
+    if (dict_bytes && !d.dict) return fail(PQD_BAD_ARG, "null dictionary");
+    if ((st = c.dict.ensure(dict_bytes + 16))) return st;
+    if (dict_bytes) PQD_HIP(hipMemcpyAsync(c.dict.p, d.dict, dict_bytes, hipMemcpyHostToDevice, nullptr));
+    d.dict = c.dict.p;
+  }
+  st = pqd_decode_pages(&d, result, 1, nullptr);
+  if (st) return st;
+  const size_t valid = (size_t)result->values_written * d.elem_size;
+  if (valid) PQD_HIP(hipMemcpyAsync(host_out, c.out.p, valid, hipMemcpyDeviceToHost, nullptr));
+  PQD_HIP(hipStreamSynchronize(nullptr));
+  return PQD_OK;
+}
+
+}  // extern "C"

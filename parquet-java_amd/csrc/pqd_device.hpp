@@ -1,0 +1,102 @@
+// Device-side helpers shared by the page-decode kernels (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pqd.h"
+
+namespace pqd {
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ({hi,lo} >> sh) & 0xffffffff for sh in 0..31 (v_alignbit_b32; sh == 0 returns lo).
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t lo, uint32_t hi, uint32_t sh) {
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// A 160-bit little-endian window held in five dwords; holds four fields of up to 32 bits (or two
+// of up to 64) at any starting bit 0..31.
+struct Window5 {
+  uint32_t d0, d1, d2, d3, d4;
+  __device__ __forceinline__ void shr(uint32_t s) {  // s in 0..31
+    d0 = funnel_shr(d0, d1, s);
+    d1 = funnel_shr(d1, d2, s);
+    d2 = funnel_shr(d2, d3, s);
+    d3 = funnel_shr(d3, d4, s);
+    d4 = d4 >> s;
+  }
+  __device__ __forceinline__ void shr32() {
+    d0 = d1;
+    d1 = d2;
+    d2 = d3;
+    d3 = d4;
+    d4 = 0;
+  }
+  // drop `w` bits, w in 0..64
+  __device__ __forceinline__ void drop(uint32_t w) {
+    if (w >= 32) {
+      shr32();
+      w -= 32;
+    }
+    if (w >= 32) {
+      shr32();
+      w -= 32;
+    }
+    shr(w);
+  }
+};
+
+__device__ __forceinline__ uint32_t mask32(uint32_t w) {  // w in 0..32
+  return w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+}
+__device__ __forceinline__ uint64_t mask64(uint32_t w) {  // w in 0..64
+  return w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+}
+
+// Stages `nbytes_window` bytes of LDS from global memory starting at the 16-byte-aligned address
+// `gbase`; bytes at addresses >= `gend` are written as zero (so a truncated final run decodes
+// zeros, and no load touches a 16-byte block that lies wholly past the end of the page).
+template <int THREADS>
+__device__ __forceinline__ void stage_window(u32x4* lds, const uint8_t* gbase, const uint8_t* gend,
+                                             int pieces) {
+  for (int i = threadIdx.x; i < pieces; i += THREADS) {
+    const uint8_t* p = gbase + (size_t)i * 16;
+    long valid = gend - p;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (valid > 0) {
+      v = *reinterpret_cast<const u32x4*>(p);
+      if (valid < 16) {
+        // keep the first `valid` bytes
+        uint32_t full = (uint32_t)valid >> 2, rem = (uint32_t)valid & 3u;
+        uint32_t part = rem ? ((1u << (8 * rem)) - 1u) : 0u;
+        v.x = full > 0 ? v.x : (full == 0 ? v.x & part : 0u);
+        v.y = full > 1 ? v.y : (full == 1 ? v.y & part : 0u);
+        v.z = full > 2 ? v.z : (full == 2 ? v.z & part : 0u);
+        v.w = full > 3 ? v.w : (full == 3 ? v.w & part : 0u);
+      }
+    }
+    lds[i] = v;
+  }
+}
+
+__device__ __forceinline__ uint32_t lds_byte(const uint32_t* lds_words, uint32_t off) {
+  return (lds_words[off >> 2] >> ((off & 3u) * 8u)) & 0xFFu;
+}
+
+// Reads the five dwords that cover bit position `bitpos` onwards and aligns them to bit 0.
+__device__ __forceinline__ Window5 load_window(const uint32_t* words, uint32_t bitpos) {
+  uint32_t i = bitpos >> 5;
+  Window5 wnd;
+  wnd.d0 = words[i];
+  wnd.d1 = words[i + 1];
+  wnd.d2 = words[i + 2];
+  wnd.d3 = words[i + 3];
+  wnd.d4 = words[i + 4];
+  wnd.shr(bitpos & 31u);
+  return wnd;
+}
+
+}  // namespace pqd

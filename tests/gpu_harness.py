@@ -1,0 +1,95 @@
+"""Helpers for the GPU parity tests: put pages on the device, call the C ABI, fetch results."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import parquet_java_amd as pq
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+class Page:
+    def __init__(self, data, num_values, encoding, elem_size=4, bit_width=0, flags=0, dictionary=None):
+        self.data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if isinstance(data, (bytes, bytearray)) else data,
+                                         dtype=np.uint8)
+        self.num_values = int(num_values)
+        self.encoding = encoding
+        self.elem_size = elem_size
+        self.bit_width = bit_width
+        self.flags = flags
+        self.dictionary = None if dictionary is None else np.ascontiguousarray(dictionary)
+
+
+def decode_pages(pages, misalign=True, fill=0xA5):
+    """Runs one pqd_decode_pages_dev launch over `pages` (all of one encoding class).
+
+    Page bytes are packed back to back into one device blob (so most pages start at odd addresses when
+    `misalign`), followed by a guard region of 0xEE bytes; outputs are pre-filled with `fill`.
+    Returns a list of (status, values_written, bytes_consumed, out_bytes ndarray[uint8]).
+    """
+    enc, elem = pages[0].encoding, pages[0].elem_size
+    offs, pos = [], 1 if misalign else 0
+    for p in pages:
+        if not misalign:
+            pos = (pos + 15) & ~15
+        offs.append(pos)
+        pos += p.data.size
+    blob = np.full(pos + 64, 0xEE, np.uint8)
+    for p, o in zip(pages, offs):
+        blob[o:o + p.data.size] = p.data
+    d_blob = to_dev(blob)
+    out_offs, opos = [], 0
+    for p in pages:
+        out_offs.append(opos)
+        opos += (p.num_values * p.elem_size + 15) & ~15
+        opos += 16
+    d_out = torch.full((max(opos, 16),), fill, dtype=torch.uint8, device=dev())
+    dicts = {}
+    descs = []
+    for p, o, oo in zip(pages, offs, out_offs):
+        dd = 0
+        dl = 0
+        if p.dictionary is not None:
+            key = id(p.dictionary)
+            if key not in dicts:
+                dicts[key] = to_dev(p.dictionary.view(np.uint8)) if p.dictionary.size else torch.zeros(16, dtype=torch.uint8, device=dev())
+            dd = dicts[key].data_ptr()
+            dl = p.dictionary.size
+        descs.append(dict(data=d_blob.data_ptr() + o, out=d_out.data_ptr() + oo, dict=dd, data_len=p.data.size,
+                          num_values=p.num_values, dict_len=dl, encoding=p.encoding, elem_size=p.elem_size,
+                          bit_width=p.bit_width, flags=p.flags))
+    arr = pq.make_descs(descs)
+    d_descs = to_dev(pq.descs_to_numpy(arr))
+    d_res = torch.zeros(len(pages) * 16, dtype=torch.uint8, device=dev())
+    stream = torch.cuda.current_stream().cuda_stream
+    pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), len(pages), enc, elem, stream)
+    torch.cuda.synchronize()
+    status, written, consumed = pq.results_from_numpy(d_res.cpu().numpy())
+    out = d_out.cpu().numpy()
+    res = []
+    for i, (p, oo) in enumerate(zip(pages, out_offs)):
+        nbytes = p.num_values * p.elem_size
+        res.append((int(status[i]), int(written[i]), int(consumed[i]), out[oo:oo + nbytes].copy(),
+                    out[oo + nbytes:oo + ((nbytes + 15) & ~15) + 16].copy()))
+    return res
+
+
+def unpack_dev(w, packed, n, long=False, offset=0):
+    """pqd_unpack_i32_dev / _i64_dev with the input placed `offset` bytes past a 256-byte aligned address."""
+    packed = np.ascontiguousarray(packed, np.uint8)
+    buf = np.full(offset + packed.size + 32, 0xEE, np.uint8)
+    buf[offset:offset + packed.size] = packed
+    d_in = to_dev(buf)
+    d_out = torch.full((max(n, 1) + 4,), -0x5A5A5A5B, dtype=torch.int64 if long else torch.int32, device=dev())
+    f = pq.lib.pqd_unpack_i64_dev if long else pq.lib.pqd_unpack_i32_dev
+    st = f(w, d_in.data_ptr() + offset, packed.size, d_out.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    return st, out[:n], out[n:]
