@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident decode of dictionary-encoded pages (RLE/bit-packed hybrid ids).
+
+Workload (BASELINE.json configs[1], per GPU): 100 M rows of a dictionary-encoded INT32 column and 100 M
+rows of a dictionary-encoded INT64 column, 65 536-entry dictionaries (id width 16), 5 000 pages of
+20 000 values each per column (parquet-java's default page row limit), ids written as parquet-java
+writes them: 1-byte bit width, then bit-packed runs of at most 504 values with 1-byte headers.
+One step = one decode pass over both columns (two kernel launches).  Pages, dictionaries and
+outputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line (rank 0).  With N > 1 it is launched by torch.distributed.run, one rank per
+GPU; every rank decodes its own shard (row groups are independent: no collective in the data path).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import parquet_java_amd as pq  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+PAGE_VALUES = 20000
+DICT_ENTRIES = 65536
+ID_WIDTH = 16
+
+
+def build_column(n_pages, elem, seed, device):
+    """Synthesises `n_pages` dictionary-id pages on the device, laid out as parquet-java's
+    DictionaryValuesWriter.getBytes + RunLengthBitPackingHybridEncoder produce them for ids that
+    never repeat 8 times in a row: [bitWidth][header][<=63 groups * 16 bytes]... with the last group
+    of a page zero-padded.  Returns (blob, page_len, ids, dictionary, out)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ids = torch.randint(0, DICT_ENTRIES, (n_pages, PAGE_VALUES), dtype=torch.int32, device=device, generator=g)
+    groups = (PAGE_VALUES + 7) // 8
+    padded = torch.zeros((n_pages, groups * 8), dtype=torch.int16, device=device)
+    padded[:, :PAGE_VALUES] = ids.to(torch.int16)
+    payload = padded.view(torch.uint8)  # width 16, LSB first == little-endian uint16
+    runs = []
+    gleft, goff = groups, 0
+    while gleft > 0:
+        gr = min(63, gleft)
+        runs.append((goff, gr))
+        goff += gr
+        gleft -= gr
+    page_len = 1 + len(runs) + groups * 2 * 8
+    blob = torch.empty((n_pages, page_len), dtype=torch.uint8, device=device)
+    blob[:, 0] = ID_WIDTH
+    pos = 1
+    for goff, gr in runs:
+        blob[:, pos] = (gr << 1) | 1
+        blob[:, pos + 1:pos + 1 + gr * 16] = payload[:, goff * 16:(goff + gr) * 16]
+        pos += 1 + gr * 16
+    assert pos == page_len
+    dt = torch.int32 if elem == 4 else torch.int64
+    info = torch.iinfo(dt)
+    dictionary = torch.randint(info.min, info.max, (DICT_ENTRIES,), dtype=dt, device=device, generator=g)
+    out = torch.zeros((n_pages, PAGE_VALUES), dtype=dt, device=device)
+    return blob, page_len, ids, dictionary, out
+
+
+def make_descs(blob, page_len, dictionary, out, elem, device):
+    n_pages = blob.shape[0]
+    pages = []
+    for i in range(n_pages):
+        pages.append(dict(data=blob.data_ptr() + i * page_len, out=out.data_ptr() + i * PAGE_VALUES * elem,
+                          dict=dictionary.data_ptr(), data_len=page_len, num_values=PAGE_VALUES,
+                          dict_len=DICT_ENTRIES, encoding=pq.ENC_RLE_DICTIONARY, elem_size=elem))
+    arr = pq.make_descs(pages)
+    d_descs = torch.from_numpy(pq.descs_to_numpy(arr)).to(device)
+    d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
+    return d_descs, d_res
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        pq.check(pq.lib.pqd_event_create(C.byref(self.h)))
+
+    def record(self, stream):
+        pq.check(pq.lib.pqd_event_record(self.h, stream))
+
+    def sync(self):
+        pq.check(pq.lib.pqd_event_sync(self.h))
+
+    def ms_since(self, start):
+        ms = C.c_float()
+        pq.check(pq.lib.pqd_event_elapsed_ms(start.h, self.h, C.byref(ms)))
+        return ms.value
+
+
+def cpu_baseline(seconds, seed, threads=1):
+    """Times the CPU restatement of the reference decoders (oracle/) on a bounded sample of the same
+    workload: INT64 dictionary pages of 20 000 values, decoded back to back for about `seconds`."""
+    import threading
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    dic = rng.integers(-1 << 62, 1 << 62, DICT_ENTRIES).astype(np.int64)
+    pages = []
+    for _ in range(8):  # 8 distinct pages, cycled
+        ids = rng.integers(0, DICT_ENTRIES, PAGE_VALUES).astype(np.int32)
+        pages.append((orc.dict_encode_ids(ids, DICT_ENTRIES), ids))
+    st, vals = orc.dict_decode(pages[0][0], dic, PAGE_VALUES)
+    assert st == 0 and (vals == dic[pages[0][1]]).all()
+    counts = [0] * threads
+    t0 = time.perf_counter()
+
+    def work(t):
+        i = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(16):
+                orc.dict_decode(pages[i % 8][0], dic, PAGE_VALUES)  # ctypes releases the GIL
+                i += 1
+        counts[t] = i
+
+    if threads == 1:
+        work(0)
+    else:
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    n = sum(counts)
+    return {"value": round(n * PAGE_VALUES * 8 / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "values_per_s": round(n * PAGE_VALUES / dt, 1),
+            "sample": f"{n} INT64 dictionary pages x {PAGE_VALUES} values (64Ki-entry dictionary, id width 16), "
+                      f"CPU restatement of DictionaryValuesReader + RunLengthBitPackingHybridDecoder, "
+                      f"{threads} thread(s), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=5000, help="pages per column per GPU (5000 x 20000 = 100 M rows)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    pq.init(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    cols = []
+    for elem in (4, 8):
+        blob, page_len, ids, dictionary, out = build_column(args.pages, elem, 1234 + 17 * rank + elem, device)
+        d_descs, d_res = make_descs(blob, page_len, dictionary, out, elem, device)
+        cols.append(dict(elem=elem, blob=blob, page_len=page_len, ids=ids, dictionary=dictionary, out=out,
+                         descs=d_descs, res=d_res))
+    torch.cuda.synchronize()
+
+    def step():
+        for c in cols:
+            pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY,
+                                c["elem"], stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    verified = None
+    if not args.no_verify:
+        step()
+        torch.cuda.synchronize()
+        verified = True
+        for c in cols:
+            status, written, _ = pq.results_from_numpy(c["res"].cpu().numpy())
+            ok = (status == 0).all() and (written == PAGE_VALUES).all()
+            expect = c["dictionary"][c["ids"].long()]
+            ok = ok and bool(torch.equal(expect, c["out"]))
+            verified = verified and bool(ok)
+            del expect
+        for c in cols:
+            c["out"].zero_()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly `steps` steps between barriers
+    ev = [[Event(), Event()] for _ in range(args.steps)]  # brackets of the dominant (INT64) kernel
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        c = cols[0]
+        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 4, stream)
+        c = cols[1]
+        ev[k][0].record(stream)
+        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 8, stream)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    n_vals = args.pages * PAGE_VALUES
+    decoded_bytes_step = n_vals * (4 + 8)
+    encoded_bytes_col = args.pages * cols[0]["page_len"]
+    k64_ms = sum(e[1].ms_since(e[0]) for e in ev) / args.steps
+    k64_alg_bytes = encoded_bytes_col + n_vals * 8 + DICT_ENTRIES * 8
+    ms_per_step = elapsed / args.steps * 1e3
+    value = decoded_bytes_step * world / (elapsed / args.steps) / 1e9
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_rle_pages_8_dict_bytes_per_launch")
+            except Exception:
+                traffic = None
+        achieved = k64_alg_bytes / (k64_ms * 1e-3) / 1e9
+        line = {
+            "metric": "device-resident decoded GB/s (RLE/bitpack+dict INT32 pages) at 1/2/4/8 GPUs",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "configs[1]: dictionary-encoded INT32 + INT64 columns, 65536-entry dictionaries "
+                                   "(id width 16), RLE/bit-packed hybrid ids (504-value runs, uniform random ids), "
+                                   f"{args.pages} pages x {PAGE_VALUES} values per column per GPU "
+                                   f"({n_vals / 1e6:.0f} M rows x 2 columns); BINARY column not included",
+                       "pages_per_column": args.pages, "page_values": PAGE_VALUES, "dictionary_entries": DICT_ENTRIES,
+                       "sharding": "one shard per GPU, no collective"},
+            "values_per_s": round(2 * n_vals * world / (elapsed / args.steps), 1),
+            "algorithmic_GBps": round((2 * encoded_bytes_col + decoded_bytes_step) * world / (elapsed / args.steps) / 1e9, 2),
+            "verified_vs_gather": verified,
+            "roofline": {"bound": "hbm", "kernel": "k_rle_pages<8,true> (INT64 dictionary pages)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": k64_alg_bytes, "avg_launch_ms": round(k64_ms, 4)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 99, 1)
+            line["cpu_baseline_16_threads"] = cpu_baseline(min(args.cpu_seconds, 5.0), 99, 16)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

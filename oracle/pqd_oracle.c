@@ -66,24 +66,60 @@ static shift_mask get_shift(int w, int is_long, int msb_first, int byte_index, i
   return sm;
 }
 
+/* The generator bakes one (byte, shift, mask) term list per value into straight-line Java.
+ * The same lists are built once here, when the library is loaded, so the unpack loops below do
+ * the work the generated code does at run time and nothing more. */
+typedef struct {
+  uint8_t byte;
+  int8_t shift;
+  uint64_t mask;
+} unpack_term;
+typedef struct {
+  uint8_t n[8];
+  unpack_term t[8][9];
+} unpack_plan;
+static unpack_plan plan32[2][33];
+static unpack_plan plan64[2][65];
+
+static void build_plan(unpack_plan* p, int w, int is_long, int msb_first) {
+  memset(p, 0, sizeof *p);
+  for (int v = 0; v < 8; ++v) {
+    int start = v * w / 8;
+    int end = ((v + 1) * w + 7) / 8;
+    for (int b = start; b < end; ++b) {
+      shift_mask sm = get_shift(w, is_long, msb_first, b, v);
+      unpack_term* t = &p->t[v][p->n[v]++];
+      t->byte = (uint8_t)b;
+      t->shift = (int8_t)sm.shift;
+      t->mask = sm.mask;
+    }
+  }
+}
+
+__attribute__((constructor)) static void build_plans(void) {
+  for (int m = 0; m < 2; ++m) {
+    for (int w = 1; w <= 32; ++w) build_plan(&plan32[m][w], w, 0, m);
+    for (int w = 1; w <= 64; ++w) build_plan(&plan64[m][w], w, 1, m);
+  }
+}
+
 /* GEN/ByteBasedBitPackingGenerator.java:258-308 (generateUnpack), int flavour.
  * Java: out[v] = OR over bytes of ((((int)in[b]) >> / << s) & mask); the byte is
  * sign-extended, the mask removes the extension. */
 void orc_unpack8_32(int msb_first, int w, const uint8_t* in, int32_t* out) {
   if (w <= 0) return; /* :267 -- width 0 writes nothing */
+  const unpack_plan* p = &plan32[msb_first ? 1 : 0][w];
   for (int v = 0; v < 8; ++v) {
-    int start = v * w / 8;
-    int end = ((v + 1) * w + 7) / 8;
     uint32_t acc = 0;
-    for (int b = start; b < end; ++b) {
-      shift_mask sm = get_shift(w, 0, msb_first, b, v);
-      int32_t sx = (int32_t)(int8_t)in[b];
-      uint32_t t;
-      if (sm.shift < 0)
-        t = (uint32_t)(sx >> (-sm.shift)); /* arithmetic, as Java >> */
+    for (int k = 0; k < p->n[v]; ++k) {
+      const unpack_term* t = &p->t[v][k];
+      int32_t sx = (int32_t)(int8_t)in[t->byte];
+      uint32_t x;
+      if (t->shift < 0)
+        x = (uint32_t)(sx >> (-t->shift)); /* arithmetic, as Java >> */
       else
-        t = ((uint32_t)sx) << sm.shift;
-      acc |= t & (uint32_t)sm.mask;
+        x = ((uint32_t)sx) << t->shift;
+      acc |= x & (uint32_t)t->mask;
     }
     out[v] = (int32_t)acc;
   }
@@ -92,19 +128,18 @@ void orc_unpack8_32(int msb_first, int w, const uint8_t* in, int32_t* out) {
 /* same, long flavour (ByteBitPackingForLongLE/BE, widths 0..64) */
 void orc_unpack8_64(int msb_first, int w, const uint8_t* in, int64_t* out) {
   if (w <= 0) return;
+  const unpack_plan* p = &plan64[msb_first ? 1 : 0][w];
   for (int v = 0; v < 8; ++v) {
-    int start = v * w / 8;
-    int end = ((v + 1) * w + 7) / 8;
     uint64_t acc = 0;
-    for (int b = start; b < end; ++b) {
-      shift_mask sm = get_shift(w, 1, msb_first, b, v);
-      int64_t sx = (int64_t)(int8_t)in[b];
-      uint64_t t;
-      if (sm.shift < 0)
-        t = (uint64_t)(sx >> (-sm.shift));
+    for (int k = 0; k < p->n[v]; ++k) {
+      const unpack_term* t = &p->t[v][k];
+      int64_t sx = (int64_t)(int8_t)in[t->byte];
+      uint64_t x;
+      if (t->shift < 0)
+        x = (uint64_t)(sx >> (-t->shift));
       else
-        t = ((uint64_t)sx) << sm.shift;
-      acc |= t & sm.mask;
+        x = ((uint64_t)sx) << t->shift;
+      acc |= x & t->mask;
     }
     out[v] = (int64_t)acc;
   }
