@@ -1,0 +1,226 @@
+// Exploration microbenchmark (not part of the product): strategies for out[i] = dict[id[i]] with a
+// dictionary larger than LDS.  ids are uint16 in HBM (100 M), dictionary 65536 x {4,8} bytes.
+//   hipcc --offload-arch=gfx950 -O3 -o gather_bench gather_bench.hip && ./gather_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    hipError_t e = (x);                                                               \
+    if (e != hipSuccess) {                                                            \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);    \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- K0: direct gather, 4 ids per thread per step
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_direct(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
+                                                T* __restrict__ out, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < n / 4; u += stride) {
+    u32x2 p = *reinterpret_cast<const u32x2*>(ids + u * 4);
+    uint32_t id[4] = {p.x & 0xFFFF, p.x >> 16, p.y & 0xFFFF, p.y >> 16};
+    T v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 0) v[j] = dict[id[j]];
+      if (MODE == 1) v[j] = __builtin_nontemporal_load(dict + id[j]);
+      if (MODE == 2) v[j] = __hip_atomic_load(dict + id[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[u * 4 + j] = v[j];
+  }
+}
+
+// ---- K1: multi-pass LDS slices.  WG of THREADS threads holds R ids per thread in registers; the
+// dictionary is streamed through LDS in slices of S entries; each pass resolves the ids that fall
+// into the slice.  Results are stored once, coalesced.
+template <typename T, int THREADS, int R, int S, bool PRED>
+__global__ __launch_bounds__(THREADS) void k_slices(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
+                                                    uint32_t dict_len, T* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  T* lds = reinterpret_cast<T*>(lds4);
+  const size_t batch = (size_t)THREADS * R;
+  for (size_t b0 = (size_t)blockIdx.x * batch; b0 < n; b0 += (size_t)gridDim.x * batch) {
+    // each thread owns R/4 units of 4 consecutive values, units strided by THREADS
+    uint32_t id[R];
+    T v[R];
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      u32x2 p = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+      id[4 * k] = p.x & 0xFFFF;
+      id[4 * k + 1] = p.x >> 16;
+      id[4 * k + 2] = p.y & 0xFFFF;
+      id[4 * k + 3] = p.y >> 16;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0;
+    for (uint32_t s0 = 0; s0 < dict_len; s0 += S) {
+      __syncthreads();
+      // stage dict[s0 .. s0+S) into LDS, 16 bytes per lane
+      const u32x4* src = reinterpret_cast<const u32x4*>(dict + s0);
+      for (int i = threadIdx.x; i < (int)(S * sizeof(T) / 16); i += THREADS) lds4[i] = src[i];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uint32_t idx = id[r] - s0;
+        if (PRED) {
+          if (idx < (uint32_t)S) v[r] = lds[idx];
+        } else {
+          T x = lds[idx & (S - 1)];
+          v[r] = idx < (uint32_t)S ? x : v[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      if (u * 4 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[u * 4 + j] = v[4 * k + j];
+      }
+    }
+  }
+}
+
+// ---- K2: whole (small) dictionary in LDS, single pass: the ceiling of the LDS gather
+template <typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lds_full(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
+                                                      uint32_t dict_len, T* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  T* lds = reinterpret_cast<T*>(lds4);
+  const u32x4* src = reinterpret_cast<const u32x4*>(dict);
+  for (int i = threadIdx.x; i < (int)(dict_len * sizeof(T) / 16); i += THREADS) lds4[i] = src[i];
+  __syncthreads();
+  size_t stride = (size_t)gridDim.x * THREADS;
+  for (size_t u = (size_t)blockIdx.x * THREADS + threadIdx.x; u < n / 4; u += stride) {
+    u32x2 p = *reinterpret_cast<const u32x2*>(ids + u * 4);
+    uint32_t id[4] = {p.x & 0xFFFF, p.x >> 16, p.y & 0xFFFF, p.y >> 16};
+    T v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = lds[id[j] & (dict_len - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[u * 4 + j] = v[j];
+  }
+}
+
+template <typename F>
+float time_it(F f, int iters = 10) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  f();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int i = 0; i < iters; ++i) f();
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters * 1000.f;
+}
+
+template <typename T>
+void run(size_t n) {
+  const uint32_t D = 65536;
+  std::vector<uint16_t> h_ids(n);
+  uint64_t x = 88172645463325252ull;
+  for (size_t i = 0; i < n; ++i) {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    h_ids[i] = (uint16_t)(x >> 20);
+  }
+  std::vector<T> h_dict(D);
+  for (uint32_t i = 0; i < D; ++i) h_dict[i] = (T)(i * 2654435761u + 12345);
+  uint16_t* ids;
+  T *dict, *out;
+  CHECK(hipMalloc(&ids, n * 2));
+  CHECK(hipMalloc(&dict, D * sizeof(T)));
+  CHECK(hipMalloc(&out, n * sizeof(T)));
+  CHECK(hipMemcpy(ids, h_ids.data(), n * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dict, h_dict.data(), D * sizeof(T), hipMemcpyHostToDevice));
+  std::vector<T> h_out(4096);
+  auto check = [&](const char* name) {
+    CHECK(hipMemcpy(h_out.data(), out + (n - 4096), 4096 * sizeof(T), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4096; ++i)
+      if (h_out[i] != h_dict[h_ids[n - 4096 + i]]) {
+        printf("  %s MISMATCH at %d\n", name, i);
+        return;
+      }
+    CHECK(hipMemset(out, 0, n * sizeof(T)));
+  };
+  const double bytes = (double)n * (2 + sizeof(T));
+  auto report = [&](const char* name, float us) {
+    printf("  T=%zu %-44s %8.1f us  %7.1f GB/s  %6.1f Gval/s\n", sizeof(T), name, us, bytes / us / 1e3, n / us / 1e3);
+    fflush(stdout);
+  };
+  float us;
+  us = time_it([&] { hipLaunchKernelGGL((k_direct<T, 0>), dim3(256 * 16), dim3(256), 0, 0, ids, dict, out, n); });
+  check("direct");
+  report("direct gather (plain loads)", us);
+  us = time_it([&] { hipLaunchKernelGGL((k_direct<T, 1>), dim3(256 * 16), dim3(256), 0, 0, ids, dict, out, n); });
+  check("direct nt");
+  report("direct gather (nontemporal loads)", us);
+  us = time_it([&] { hipLaunchKernelGGL((k_direct<T, 2>), dim3(256 * 16), dim3(256), 0, 0, ids, dict, out, n); });
+  check("direct sc1");
+  report("direct gather (agent-scope relaxed loads)", us);
+  us = time_it([&] { hipLaunchKernelGGL((k_direct<T, 0>), dim3(256 * 32), dim3(256), 0, 0, ids, dict, out, n); });
+  check("direct 32/CU");
+  report("direct gather, grid 32 WG/CU", us);
+
+#define SL(THREADS, R, S, PRED, WGS)                                                                            \
+  {                                                                                                             \
+    size_t lds = (size_t)S * sizeof(T);                                                                         \
+    CHECK(hipFuncSetAttribute((const void*)k_slices<T, THREADS, R, S, PRED>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    us = time_it([&] {                                                                                          \
+      hipLaunchKernelGGL((k_slices<T, THREADS, R, S, PRED>), dim3(256 * WGS), dim3(THREADS), lds, 0, ids, dict, \
+                         D, out, n);                                                                            \
+    });                                                                                                         \
+    check("slices");                                                                                            \
+    char nm[128];                                                                                               \
+    snprintf(nm, sizeof nm, "LDS slices thr=%d R=%d S=%d pred=%d wg/cu=%d", THREADS, R, S, (int)PRED, WGS);     \
+    report(nm, us);                                                                                             \
+  }
+  SL(1024, 32, 16384, true, 1);
+  SL(1024, 32, 16384, false, 1);
+  SL(1024, 16, 16384, true, 1);
+  SL(512, 32, 8192, true, 2);
+  SL(512, 32, 8192, false, 2);
+  SL(1024, 32, 8192, true, 2);
+  SL(256, 32, 4096, true, 8);
+  SL(256, 32, 4096, false, 8);
+  if (sizeof(T) == 4) {
+    SL(1024, 32, 32768, true, 1);
+    SL(1024, 32, 32768, false, 1);
+  }
+  // ceiling: a 16 K-entry dictionary wholly in LDS
+  {
+    const uint32_t small = 16384;
+    size_t lds = small * sizeof(T);
+    CHECK(hipFuncSetAttribute((const void*)k_lds_full<T, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    us = time_it([&] { hipLaunchKernelGGL((k_lds_full<T, 256>), dim3(256 * 2), dim3(256), lds, 0, ids, dict, small, out, n); });
+    report("whole 16K-entry dict in LDS (ceiling)", us);
+    CHECK(hipMemset(out, 0, n * sizeof(T)));
+  }
+  CHECK(hipFree(ids));
+  CHECK(hipFree(dict));
+  CHECK(hipFree(out));
+}
+
+int main() {
+  size_t n = 100000000;
+  run<uint32_t>(n);
+  run<uint64_t>(n);
+  return 0;
+}
