@@ -92,6 +92,119 @@ __global__ __launch_bounds__(THREADS) void k_slices(const uint16_t* __restrict__
   }
 }
 
+
+// ---- K3: K1 with double-buffered slices staged by LDS-DMA (global_load_lds_dwordx4), one barrier per pass
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <typename T, int THREADS, int S>
+__device__ __forceinline__ void prefetch_slice(const T* dict, uint32_t s0, T* buf) {
+  // S*sizeof(T)/16 pieces of 16 bytes; a wave instruction moves 64 pieces (1 KiB)
+  const int pieces = S * sizeof(T) / 16;
+  const char* src = reinterpret_cast<const char*>(dict + s0);
+  char* dst = reinterpret_cast<char*>(buf);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < pieces / THREADS; ++i) {
+    const int piece0 = i * THREADS + wave * 64;  // wave-uniform
+    __builtin_amdgcn_global_load_lds((gbl_void*)(src + (size_t)(piece0 + lane) * 16), (lds_void*)(dst + (size_t)piece0 * 16),
+                                     16, 0, 0);
+  }
+}
+
+template <typename T, int THREADS, int R, int S>
+__global__ __launch_bounds__(THREADS) void k_slices_db(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
+                                                       uint32_t dict_len, T* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  T* lds = reinterpret_cast<T*>(lds4);
+  const size_t batch = (size_t)THREADS * R;
+  const uint32_t P = dict_len / S;
+  uint32_t q = 0;  // pass counter; buffer q&1 holds slice q%P
+  prefetch_slice<T, THREADS, S>(dict, 0, lds);
+  for (size_t b0 = (size_t)blockIdx.x * batch; b0 < n; b0 += (size_t)gridDim.x * batch) {
+    uint32_t id[R];
+    T v[R];
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      u32x2 p = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+      id[4 * k] = p.x & 0xFFFF;
+      id[4 * k + 1] = p.x >> 16;
+      id[4 * k + 2] = p.y & 0xFFFF;
+      id[4 * k + 3] = p.y >> 16;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0;
+    for (uint32_t s = 0; s < P; ++s, ++q) {
+      __syncthreads();  // slice q landed (vmcnt(0) + barrier); everyone is done with the other buffer
+      const uint32_t nxt = (s + 1 == P) ? 0 : s + 1;
+      prefetch_slice<T, THREADS, S>(dict, nxt * S, lds + (size_t)((q + 1) & 1) * S);
+      const T* cur = lds + (size_t)(q & 1) * S;
+      const uint32_t s0 = s * S;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uint32_t idx = id[r] - s0;
+        if (idx < (uint32_t)S) v[r] = cur[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      if (u * 4 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[u * 4 + j] = v[4 * k + j];
+      }
+    }
+  }
+}
+
+
+// ---- K4: K3 with ids kept packed (two 16-bit ids per register)
+template <typename T, int THREADS, int R, int S>
+__global__ __launch_bounds__(THREADS) void k_slices_dbp(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
+                                                        uint32_t dict_len, T* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  T* lds = reinterpret_cast<T*>(lds4);
+  const size_t batch = (size_t)THREADS * R;
+  const uint32_t P = dict_len / S;
+  uint32_t q = 0;
+  prefetch_slice<T, THREADS, S>(dict, 0, lds);
+  for (size_t b0 = (size_t)blockIdx.x * batch; b0 < n; b0 += (size_t)gridDim.x * batch) {
+    uint32_t idp[R / 2];
+    T v[R];
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      u32x2 p = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+      idp[2 * k] = p.x;
+      idp[2 * k + 1] = p.y;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0;
+    for (uint32_t s = 0; s < P; ++s, ++q) {
+      __syncthreads();
+      const uint32_t nxt = (s + 1 == P) ? 0 : s + 1;
+      prefetch_slice<T, THREADS, S>(dict, nxt * S, lds + (size_t)((q + 1) & 1) * S);
+      const T* cur = lds + (size_t)(q & 1) * S;
+      const uint32_t s0 = s * S;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        uint32_t id = (r & 1) ? (idp[r >> 1] >> 16) : (idp[r >> 1] & 0xFFFF);
+        uint32_t idx = id - s0;
+        if (idx < (uint32_t)S) v[r] = cur[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      size_t u = b0 / 4 + (size_t)k * THREADS + threadIdx.x;
+      if (u * 4 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[u * 4 + j] = v[4 * k + j];
+      }
+    }
+  }
+}
+
 // ---- K2: whole (small) dictionary in LDS, single pass: the ceiling of the LDS gather
 template <typename T, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_lds_full(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
@@ -203,6 +316,56 @@ void run(size_t n) {
   if (sizeof(T) == 4) {
     SL(1024, 32, 32768, true, 1);
     SL(1024, 32, 32768, false, 1);
+  }
+
+#define SLDB(THREADS, R, S, WGS)                                                                                 \
+  {                                                                                                              \
+    size_t lds = (size_t)2 * S * sizeof(T);                                                                      \
+    CHECK(hipFuncSetAttribute((const void*)k_slices_db<T, THREADS, R, S>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    us = time_it([&] {                                                                                           \
+      hipLaunchKernelGGL((k_slices_db<T, THREADS, R, S>), dim3(256 * WGS), dim3(THREADS), lds, 0, ids, dict, D,   \
+                         out, n);                                                                                \
+    });                                                                                                          \
+    check("slices db");                                                                                          \
+    char nm[128];                                                                                                \
+    snprintf(nm, sizeof nm, "LDS-DMA double-buffered thr=%d R=%d S=%d wg/cu=%d", THREADS, R, S, WGS);             \
+    report(nm, us);                                                                                              \
+  }
+  SLDB(1024, 32, 8192, 1);
+  SLDB(1024, 20, 8192, 1);
+  SLDB(1024, 32, 4096, 1);
+  SLDB(512, 32, 4096, 2);
+  SLDB(512, 32, 8192, 1);
+  if (sizeof(T) == 4) {
+    SLDB(1024, 32, 16384, 1);
+    SLDB(1024, 20, 16384, 1);
+  }
+
+#define SLDBP(THREADS, R, S, WGS)                                                                                \
+  {                                                                                                              \
+    size_t lds = (size_t)2 * S * sizeof(T);                                                                      \
+    CHECK(hipFuncSetAttribute((const void*)k_slices_dbp<T, THREADS, R, S>,                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    us = time_it([&] {                                                                                           \
+      hipLaunchKernelGGL((k_slices_dbp<T, THREADS, R, S>), dim3(256 * WGS), dim3(THREADS), lds, 0, ids, dict, D,  \
+                         out, n);                                                                                \
+    });                                                                                                          \
+    check("slices dbp");                                                                                         \
+    char nm[128];                                                                                                \
+    snprintf(nm, sizeof nm, "packed-id dbuf thr=%d R=%d S=%d wg/cu=%d", THREADS, R, S, WGS);                      \
+    report(nm, us);                                                                                              \
+  }
+  SLDBP(1024, 32, 8192, 1);
+  SLDBP(1024, 24, 8192, 1);
+  SLDBP(512, 64, 8192, 1);
+  SLDBP(512, 48, 8192, 1);
+  SLDBP(512, 40, 8192, 1);
+  SLDBP(256, 128, 8192, 1);
+  if (sizeof(T) == 4) {
+    SLDBP(1024, 32, 16384, 1);
+    SLDBP(512, 64, 16384, 1);
+    SLDBP(512, 40, 16384, 1);
   }
   // ceiling: a 16 K-entry dictionary wholly in LDS
   {
