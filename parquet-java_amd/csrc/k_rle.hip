@@ -18,6 +18,7 @@
 // HBM-bound: w/8 bytes in + elem bytes out per value; the dictionary is read through L2.
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
+#include "pqd_rle_plan.hpp"
 
 namespace pqd {
 
@@ -235,7 +236,8 @@ __device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg
 template <int ELEM, bool HAS_DICT>
 __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
                                                            pqd_page_result* __restrict__ results,
-                                                           uint32_t n_pages) {
+                                                           uint32_t n_pages,
+                                                           const RlePagePlan* __restrict__ only_fallback) {
   __shared__ u32x4 win4[WINDOW_PIECES];
   __shared__ uint32_t seg_start[MAX_SEGS + 1];
   __shared__ uint32_t seg_src[MAX_SEGS];
@@ -245,6 +247,8 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
 
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
+  // when a plan array is given, only the pages the planned path could not take are decoded here
+  if (only_fallback && !(only_fallback[page].flags & PLAN_F_FALLBACK)) return;
   const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
 
@@ -418,21 +422,19 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
   }
 }
 
-template __global__ void k_rle_pages<4, false>(const pqd_page_desc*, pqd_page_result*, uint32_t);
-template __global__ void k_rle_pages<4, true>(const pqd_page_desc*, pqd_page_result*, uint32_t);
-template __global__ void k_rle_pages<8, true>(const pqd_page_desc*, pqd_page_result*, uint32_t);
 
 
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
-                            bool has_dict, hipStream_t stream) {
+                            bool has_dict, const void* only_fallback_plans, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   const dim3 grid(n_pages), block(RLE_THREADS);
+  const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
   if (!has_dict)
-    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl);
   else if (elem == 4)
-    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl);
   else
-    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl);
   return hipGetLastError();
 }
 

@@ -1,0 +1,369 @@
+// Header walk of RLE / bit-packing hybrid pages: one wave per page, thousands of pages in flight.
+//
+// Follows RunLengthBitPackingHybridDecoder.readNext (parquet-column/.../values/rle/
+// RunLengthBitPackingHybridDecoder.java:80-109) run by run, but instead of unpacking it records
+// where each run's values come from (pqd_rle_plan.hpp).  Stream prefixes are handled here too:
+// the 4-byte length of RunLengthBitPackingHybridValuesReader (:41-45) and the 1-byte width of
+// DictionaryValuesReader (parquet-column/.../values/dictionary/DictionaryValuesReader.java:49-63).
+//
+// Only header bytes are touched (a few bytes per run); the payload is never read here.  The wave
+// fetches headers speculatively: each of its 64 lanes loads 16 bytes at pos + lane*stride, where
+// stride is the length of the run just walked (16 while nothing is known, which makes the 64
+// blocks one contiguous KiB).  Pages written by parquet-java consist of equal-length 504-value
+// runs, so one such round brings in every remaining header of the page; irregular pages simply
+// take more rounds.  Latency-bound by design: the chip hides it by running one wave per page for
+// every page of the batch at once.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+#include "pqd_rle_plan.hpp"
+
+namespace pqd {
+
+constexpr int PLAN_THREADS = 64;
+constexpr int PLAN_SLOTS = 64;       // 16-byte header blocks fetched per round, one per lane
+constexpr uint32_t PLAN_NEED = 9;    // bytes a header can need: 5 (varint) + 4 (RLE value)
+
+struct PlanState {
+  uint32_t pos;       // next unread stream byte
+  uint32_t vals;      // values planned so far
+  uint32_t pending;   // groups left of a bit-packed run whose header is consumed
+  uint32_t nstage;    // segments waiting in the LDS stage
+  int32_t status;
+  uint32_t done;
+  uint32_t need_round;  // the walk needs header bytes that the last round did not fetch
+  uint32_t round_pos0;  // stream offset of block 0 of the last round
+  uint32_t round_stride;
+  uint32_t next_stride; // length of the last run walked: stride of the next round
+  uint32_t chunk_slot;  // pool chunk obtained for the flush in progress
+};
+
+// One lane.  Emits segments into `stage` until the stage is full, the walk leaves the header
+// window, or the page is finished.
+__device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uint32_t w, uint32_t end,
+                          uint32_t n_values, uint32_t seg_groups_cap) {
+  uint32_t pos = st.pos, vals = st.vals, pending = st.pending, ns = st.nstage;
+  const uint32_t pos0 = st.round_pos0, stride = st.round_stride;
+  uint32_t blk = 0, blk_pos = pos0, next_stride = st.next_stride;  // block that may hold the next header
+  int32_t status = PQD_OK;
+  bool need_round = false;
+  while (ns < SEG_CHUNK && vals < n_values) {
+    const uint32_t rem = n_values - vals;
+    if (pending == 0) {
+      if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
+        status = PQD_PAST_END;
+        break;
+      }
+      // the header (<= 5 bytes) and an RLE value (<= 4 bytes) must lie inside a fetched block
+      uint32_t off;  // LDS byte offset of stream byte `pos`
+      if (stride == 16) {
+        const bool inside = pos >= pos0 && (pos + PLAN_NEED <= pos0 + 16 * PLAN_SLOTS || pos0 + 16 * PLAN_SLOTS >= end);
+        if (!inside) {
+          need_round = true;
+          break;
+        }
+        off = pos - pos0;
+      } else {
+        while (blk + 1 < (uint32_t)PLAN_SLOTS && blk_pos + stride <= pos) {
+          ++blk;
+          blk_pos += stride;
+        }
+        const bool inside = pos >= blk_pos && (pos + PLAN_NEED <= blk_pos + 16 || (blk_pos + 16 >= end && pos < blk_pos + 16));
+        if (!inside) {
+          need_round = true;
+          break;
+        }
+        off = blk * 16 + (pos - blk_pos);
+      }
+      const uint32_t run_pos = pos;
+      // BytesUtils.readUnsignedVarInt (parquet-common/.../BytesUtils.java:202-211)
+      uint32_t header = 0, shift = 0, p = pos, nb = 0;
+      for (;;) {
+        if (p >= end) {
+          status = PQD_EOF;
+          break;
+        }
+        if (++nb > 10) {  // over-long varint: no writer produces it
+          status = PQD_DECODE;
+          break;
+        }
+        const uint32_t b = lds_byte(win, off + (p - run_pos));
+        ++p;
+        if (b & 0x80u) {
+          header |= (b & 0x7Fu) << (shift & 31u);
+          shift += 7;
+        } else {
+          header |= b << (shift & 31u);
+          break;
+        }
+      }
+      if (status) break;
+      if ((header & 1u) == 0) {
+        // RLE run; the value is ceil(w/8) little-endian bytes, not masked (BytesUtils.java:124-142)
+        const uint32_t count = header >> 1;
+        const uint32_t nbytes = (w + 7) >> 3;
+        if (end - p < nbytes) {
+          status = PQD_EOF;
+          break;
+        }
+        uint32_t value = 0;
+        for (uint32_t i = 0; i < nbytes; ++i) value |= lds_byte(win, off + (p - run_pos) + i) << (8 * i);
+        pos = p + nbytes;
+        next_stride = pos - run_pos;
+        // a zero-count run leaves currentCount negative: its value repeats for the rest of the page
+        const uint32_t take = (count == 0 || count > rem) ? rem : count;
+        stage[ns].start_kind = vals;
+        stage[ns].src = value;
+        ++ns;
+        vals += take;
+        continue;
+      }
+      const uint32_t groups = header >> 1;
+      if (groups == 0 || groups > 0x0FFFFFFFu) {  // empty buffer indexed / negative array size
+        status = PQD_DECODE;
+        break;
+      }
+      pending = groups;
+      pos = p;
+      const uint64_t run_len = (uint64_t)groups * w + (p - run_pos);
+      next_stride = run_len > 0x40000000ull ? 0x40000000u : (uint32_t)run_len;
+    }
+    // ---- a piece of the current bit-packed run
+    const uint32_t want = (rem + 7) >> 3;
+    uint32_t g = pending < want ? pending : want;
+    const uint32_t avail = end > pos ? end - pos : 0u;
+    bool zeros = (w == 0);
+    if (!zeros) {
+      if (g > seg_groups_cap) g = seg_groups_cap;
+      if ((uint64_t)g * w > avail) {
+        const uint32_t with_data = (avail + w - 1) / w;  // groups holding at least one real byte
+        if (with_data == 0)
+          zeros = true;  // the stream ended inside the run: the rest of its buffer stays zero (:95-99)
+        else
+          g = with_data;
+      }
+    }
+    if (zeros) {
+      g = pending < want ? pending : want;
+      const uint32_t take = g * 8 > rem ? rem : g * 8;
+      stage[ns].start_kind = vals;
+      stage[ns].src = 0;
+      ++ns;
+      vals += take;
+      pending = 0;
+      continue;
+    }
+    const uint32_t bytes = g * w;
+    const uint32_t take = g * 8 > rem ? rem : g * 8;
+    stage[ns].start_kind = vals | SEG_PACKED_BIT | (bytes > avail ? SEG_PARTIAL_BIT : 0u);
+    stage[ns].src = pos;
+    ++ns;
+    vals += take;
+    pos += bytes > avail ? avail : bytes;
+    pending -= g;
+  }
+  if (status != PQD_OK) {
+    st.status = status;
+    st.done = 1;
+  } else if (vals >= n_values) {
+    if (pending > 0 && w > 0) {  // readNext consumed the whole payload when it read the header
+      const uint64_t rest = (uint64_t)pending * w;
+      const uint32_t avail = end > pos ? end - pos : 0u;
+      pos += rest > avail ? avail : (uint32_t)rest;
+    }
+    st.done = 1;
+  }
+  st.pos = pos;
+  st.vals = vals;
+  st.pending = pending;
+  st.nstage = ns;
+  st.need_round = need_round ? 1u : 0u;
+  st.next_stride = next_stride;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* __restrict__ descs,
+                                                           pqd_page_result* __restrict__ results,
+                                                           RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
+                                                           uint32_t pool_chunks, uint32_t* __restrict__ pool_cursor,
+                                                           uint32_t n_pages, int want_dict, int elem) {
+  __shared__ u32x4 win4[PLAN_SLOTS + 1];
+  __shared__ RleSeg stage[SEG_CHUNK];
+  __shared__ PlanState st;
+  __shared__ uint32_t chunk_list[MAX_PLAN_CHUNKS];
+  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_page_desc d = descs[page];
+  const uint32_t tid = threadIdx.x;
+
+  // ---- validation and stream prefixes (same rules as the generic kernel)
+  int32_t early = PQD_OK;
+  bool finished = false;
+  uint32_t pos = 0, end = d.data_len, w = d.bit_width, consumed_override = ~0u;
+  const uint32_t n_values = d.num_values;
+  const bool is_dict = d.encoding == PQD_ENC_RLE_DICTIONARY;
+  if ((d.encoding != PQD_ENC_RLE && !is_dict) || (int)is_dict != want_dict || (int)d.elem_size != elem) {
+    early = PQD_BAD_ARG;
+    finished = true;
+  } else if (is_dict || (d.flags & PQD_F_WIDTH_PREFIX)) {
+    if (end == 0) {
+      early = n_values ? PQD_DECODE : PQD_OK;
+      finished = true;
+    } else {
+      w = d.data[0];
+      pos = 1;
+    }
+  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
+    if (end < 4) {
+      early = PQD_EOF;
+      finished = true;
+    } else {
+      const uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) |
+                           ((uint32_t)d.data[3] << 24);
+      if ((int32_t)len < 0) {
+        early = PQD_DECODE;
+        finished = true;
+      } else if (len > end - 4) {
+        early = PQD_EOF;
+        finished = true;
+      } else {
+        pos = 4;
+        end = 4 + len;
+        consumed_override = end;
+      }
+    }
+  }
+  if (!finished && w > 32) {
+    early = PQD_BAD_ARG;
+    finished = true;
+  }
+  if (finished || n_values == 0) {
+    if (tid == 0) {
+      pqd_page_result r;
+      r.status = early;
+      r.values_written = 0;
+      r.bytes_consumed = early == PQD_OK ? (consumed_override != ~0u ? consumed_override : pos) : 0;
+      r.reserved = 0;
+      results[page] = r;
+      RlePagePlan pl = {};
+      pl.status = early;
+      pl.flags = PLAN_F_DONE;
+      pl.w = w;
+      plans[page] = pl;
+    }
+    return;
+  }
+
+  if (n_values > SEG_START_MASK) {  // segment start indices hold 30 bits: leave such pages to the generic kernel
+    if (tid == 0) {
+      RlePagePlan pl = {};
+      pl.flags = PLAN_F_FALLBACK;
+      plans[page] = pl;
+    }
+    return;
+  }
+  if (tid == 0) {
+    st.pos = pos;
+    st.vals = 0;
+    st.pending = 0;
+    st.nstage = 0;
+    st.status = PQD_OK;
+    st.done = 0;
+    st.need_round = 1;
+    st.round_pos0 = pos;
+    st.round_stride = 16;
+    st.next_stride = 16;
+    st.chunk_slot = 0;
+  }
+  __syncthreads();
+
+    const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
+  uint32_t nchunks = 0, nseg = 0;
+  bool fallback = false;
+  for (;;) {
+    if (st.need_round) {
+      // one round: lane l fetches the 16 bytes at pos + l*stride (bytes past the stream end read as zero)
+      const uint32_t cur = st.pos;
+      const uint32_t stride = st.next_stride < 24 ? 16u : st.next_stride;
+      const uint64_t at = (uint64_t)cur + (uint64_t)tid * stride;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (at + 16 <= end) {
+        __builtin_memcpy(&v, d.data + at, 16);
+      } else if (at < end) {
+        uint32_t tmp[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t i = 0; i < (uint32_t)(end - at); ++i) tmp[i >> 2] |= (uint32_t)d.data[at + i] << (8 * (i & 3u));
+        v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+      }
+      __syncthreads();
+      win4[tid] = v;
+      if (tid == 0) {
+        win4[PLAN_SLOTS] = u32x4{0u, 0u, 0u, 0u};
+        st.round_pos0 = cur;
+        st.round_stride = stride;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap);
+    __syncthreads();
+    const uint32_t ns = st.nstage;
+    const bool done = st.done != 0;
+    if (ns == SEG_CHUNK || (done && ns > 0)) {
+      // flush the stage to a pool chunk
+      if (tid == 0) {
+        // chunk 0 of page p is pool chunk p (readable without the plan); the rest come from the shared tail
+        uint32_t slot = ~0u;
+        if (nchunks == 0) {
+          slot = page;
+        } else if (nchunks < (uint32_t)MAX_PLAN_CHUNKS) {
+          slot = n_pages + atomicAdd(pool_cursor, 1u);
+          if (slot >= pool_chunks) slot = ~0u;
+        }
+        st.chunk_slot = slot;
+        st.nstage = 0;
+      }
+      __syncthreads();
+      const uint32_t slot = st.chunk_slot;
+      if (slot == ~0u) {
+        fallback = true;
+        break;
+      }
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (size_t)slot * SEG_CHUNK);
+      for (uint32_t i = tid; i < ns * 2; i += PLAN_THREADS) dst[i] = src[i];
+      if (tid == 0) chunk_list[nchunks] = slot;
+      ++nchunks;
+      nseg += ns;
+      __syncthreads();
+    }
+    if (done) break;
+  }
+  if (tid == 0) {
+    RlePagePlan pl = {};
+    pl.status = st.status;
+    pl.n_out = st.vals;
+    pl.consumed = consumed_override != ~0u ? consumed_override : st.pos;
+    pl.nseg = nseg;
+    pl.w = w;
+    pl.flags = fallback ? PLAN_F_FALLBACK : 0u;
+    pl.nchunks = nchunks;
+    pl.stream_end = end;  // bytes at or past it read as zero
+    pl.data = (uint64_t)(uintptr_t)d.data;
+    pl.out = (uint64_t)(uintptr_t)d.out;
+    pl.dict = (uint64_t)(uintptr_t)d.dict;
+    pl.dict_len = d.dict_len;
+    pl.data_len = d.data_len;
+    for (uint32_t i = 0; i < nchunks; ++i) pl.chunk[i] = chunk_list[i];
+    plans[page] = pl;
+  }
+}
+
+hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
+                           uint32_t pool_chunks, uint32_t* pool_cursor, uint32_t n_pages, bool want_dict, int elem,
+                           hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rle_plan, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
+                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, pool_cursor,
+                     n_pages, want_dict ? 1 : 0, elem);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

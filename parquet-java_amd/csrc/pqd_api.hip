@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -66,6 +68,51 @@ int check_device_available() {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return fail(PQD_NO_DEVICE, "no HIP device visible");
   return PQD_OK;
+}
+
+// Device scratch of the planned RLE path: run plans, the segment pool and its allocation counter.
+// One per (device, stream): calls on one stream are ordered, calls on different streams must not
+// share it.  Grown on demand, never shrunk, released with the process.
+struct PlanScratch {
+  void* plans = nullptr;
+  void* pool = nullptr;
+  uint32_t* cursor = nullptr;
+  uint32_t cap_pages = 0, cap_chunks = 0;
+};
+std::mutex g_plan_mutex;
+std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
+
+int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
+  int dev = 0;
+  PQD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  PlanScratch& ps = g_plan_scratch[std::make_pair(dev, (void*)stream)];
+  const uint32_t want_chunks = n_pages * 2 + 1024;  // chunk p belongs to page p, the rest is shared
+  if (ps.cap_pages < n_pages || ps.cap_chunks < want_chunks) {
+    // wait for work that may still use the old buffers, then replace them
+    PQD_HIP(hipStreamSynchronize(stream));
+    if (ps.plans) (void)hipFree(ps.plans);
+    if (ps.pool) (void)hipFree(ps.pool);
+    ps.plans = ps.pool = nullptr;
+    ps.cap_pages = ps.cap_chunks = 0;
+    const uint32_t pages = n_pages + n_pages / 4 + 64;
+    const uint32_t chunks = pages * 2 + 1024;
+    PQD_HIP(hipMalloc(&ps.plans, (size_t)pages * 128));
+    PQD_HIP(hipMalloc(&ps.pool, (size_t)chunks * 128 * 8));
+    if (!ps.cursor) PQD_HIP(hipMalloc((void**)&ps.cursor, 256));
+    ps.cap_pages = pages;
+    ps.cap_chunks = chunks;
+  }
+  *out = ps;
+  return PQD_OK;
+}
+
+// Which kernels decode dictionary pages.  PQD_DICT_PATH=sliced selects the planned path (header-walk
+// kernel + LDS-sliced gather); anything else, or nothing, the single generic kernel.  Read on every
+// call so that a test can switch between the two inside one process.
+bool use_sliced_dictionary_path() {
+  const char* v = getenv("PQD_DICT_PATH");
+  return v && strcmp(v, "sliced") == 0;
 }
 
 int class_of(const pqd_page_desc& d) {  // pages that can share a launch
@@ -264,11 +311,25 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
   switch (encoding) {
     case PQD_ENC_RLE:
       if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_RLE produces 4-byte values");
-      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, s));
+      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, nullptr, s));
       return PQD_OK;
     case PQD_ENC_RLE_DICTIONARY:
       if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");
-      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, s));
+      if (!use_sliced_dictionary_path()) {
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, nullptr, s));
+      } else {
+        // 1. header walk of every page (one wave per page) -> run plans in scratch
+        // 2. expansion + sliced LDS gather of the planned pages
+        // 3. generic kernel for the pages whose plan did not fit the scratch
+        PlanScratch ps;
+        int st = plan_scratch_for(s, n_pages, &ps);
+        if (st) return st;
+        PQD_HIP(hipMemsetAsync(ps.cursor, 0, 256, s));
+        PQD_HIP(pqd::launch_rle_plan(descs, results, ps.plans, ps.pool, ps.cap_chunks, ps.cursor, n_pages, true,
+                                     elem_size, s));
+        PQD_HIP(pqd::launch_dict_pages_sliced(descs, results, ps.plans, ps.pool, n_pages, elem_size, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, s));
+      }
       return PQD_OK;
     case PQD_ENC_DELTA_BINARY_PACKED:
       if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "delta values must be 4 or 8 bytes");

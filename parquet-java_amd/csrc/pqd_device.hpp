@@ -11,6 +11,7 @@ namespace pqd {
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ({hi,lo} >> sh) & 0xffffffff for sh in 0..31 (v_alignbit_b32; sh == 0 returns lo).
 __device__ __forceinline__ uint32_t funnel_shr(uint32_t lo, uint32_t hi, uint32_t sh) {
@@ -56,29 +57,41 @@ __device__ __forceinline__ uint64_t mask64(uint32_t w) {  // w in 0..64
   return w >= 64 ? ~0ull : ((1ull << w) - 1ull);
 }
 
-// Stages `nbytes_window` bytes of LDS from global memory starting at the 16-byte-aligned address
+// Stages `pieces` 16-byte pieces of LDS from global memory starting at the 16-byte-aligned address
 // `gbase`; bytes at addresses >= `gend` are written as zero (so a truncated final run decodes
 // zeros, and no load touches a 16-byte block that lies wholly past the end of the page).
+// Four independent loads are issued per lane before the first is consumed.
+__device__ __forceinline__ u32x4 keep_leading_bytes(u32x4 v, long valid) {
+  if (valid >= 16) return v;
+  if (valid <= 0) return u32x4{0u, 0u, 0u, 0u};
+  const uint32_t full = (uint32_t)valid >> 2, rem = (uint32_t)valid & 3u;
+  const uint32_t part = rem ? ((1u << (8 * rem)) - 1u) : 0u;
+  v.x = full > 0 ? v.x : v.x & part;
+  v.y = full > 1 ? v.y : (full == 1 ? v.y & part : 0u);
+  v.z = full > 2 ? v.z : (full == 2 ? v.z & part : 0u);
+  v.w = full > 3 ? v.w : (full == 3 ? v.w & part : 0u);
+  return v;
+}
+
 template <int THREADS>
 __device__ __forceinline__ void stage_window(u32x4* lds, const uint8_t* gbase, const uint8_t* gend,
                                              int pieces) {
-  for (int i = threadIdx.x; i < pieces; i += THREADS) {
-    const uint8_t* p = gbase + (size_t)i * 16;
-    long valid = gend - p;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (valid > 0) {
-      v = *reinterpret_cast<const u32x4*>(p);
-      if (valid < 16) {
-        // keep the first `valid` bytes
-        uint32_t full = (uint32_t)valid >> 2, rem = (uint32_t)valid & 3u;
-        uint32_t part = rem ? ((1u << (8 * rem)) - 1u) : 0u;
-        v.x = full > 0 ? v.x : (full == 0 ? v.x & part : 0u);
-        v.y = full > 1 ? v.y : (full == 1 ? v.y & part : 0u);
-        v.z = full > 2 ? v.z : (full == 2 ? v.z & part : 0u);
-        v.w = full > 3 ? v.w : (full == 3 ? v.w & part : 0u);
-      }
+  for (int i0 = threadIdx.x; i0 < pieces; i0 += THREADS * 4) {
+    u32x4 v[4];
+    long valid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j * THREADS;
+      const uint8_t* p = gbase + (size_t)i * 16;
+      valid[j] = i < pieces ? (long)(gend - p) : 0;
+      v[j] = u32x4{0u, 0u, 0u, 0u};
+      if (valid[j] > 0) v[j] = *reinterpret_cast<const u32x4*>(p);
     }
-    lds[i] = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j * THREADS;
+      if (i < pieces) lds[i] = keep_leading_bytes(v[j], valid[j]);
+    }
   }
 }
 

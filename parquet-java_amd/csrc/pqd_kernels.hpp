@@ -13,8 +13,17 @@ hipError_t launch_unpack_run_i32(const uint8_t* in, uint64_t in_bytes, int32_t* 
 hipError_t launch_unpack_run_i64(const uint8_t* in, uint64_t in_bytes, int64_t* out, uint64_t n_values,
                                  uint32_t w, hipStream_t stream);
 // elem: 4 or 8; has_dict: PQD_ENC_RLE_DICTIONARY pages
+// only_fallback_plans: nullptr = decode every page; else decode only pages whose plan is flagged for fallback
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
-                            bool has_dict, hipStream_t stream);
+                            bool has_dict, const void* only_fallback_plans, hipStream_t stream);
+// header walk -> run plans (pqd_rle_plan.hpp); `plans` holds n_pages records of 128 bytes, `pool`
+// pool_chunks chunks of 128 segments of 12 bytes, `pool_cursor` a zeroed counter
+hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
+                           uint32_t pool_chunks, uint32_t* pool_cursor, uint32_t n_pages, bool want_dict, int elem,
+                           hipStream_t stream);
+// planned dictionary pages: expansion + sliced LDS gather
+hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
+                                    const void* pool, uint32_t n_pages, int elem, hipStream_t stream);
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream);
 hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,

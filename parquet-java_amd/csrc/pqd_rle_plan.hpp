@@ -1,0 +1,50 @@
+// Run plan of an RLE / bit-packing hybrid page: the output of the header-walk kernel
+// (k_rle_plan) and the input of the expansion kernels.
+//
+// The hybrid grammar is sequential (each run header sits right behind the previous run's
+// payload), so finding the runs is a pointer chase.  It is done once per page by a single wave,
+// thousands of pages at a time, and leaves a table of segments in device scratch memory; the
+// kernels that move the bulk of the bytes then start from the table and contain no serial code.
+#pragma once
+
+#include <stdint.h>
+
+namespace pqd {
+
+// One segment = a run, or a piece of a bit-packed run, whose values are consecutive in the output.
+struct RleSeg {
+  uint32_t start_kind;  // bits 0..29: output index of the first value; bit 31: bit-packed;
+                        // bit 30: bit-packed and cut short by the end of the stream (missing bytes are zero)
+  uint32_t src;         // bit-packed: stream offset of the first group; RLE: the repeated value
+};
+
+constexpr uint32_t SEG_PACKED_BIT = 0x80000000u;
+constexpr uint32_t SEG_PARTIAL_BIT = 0x40000000u;
+constexpr uint32_t SEG_START_MASK = 0x3FFFFFFFu;
+constexpr int SEG_CHUNK = 128;            // segments per pool chunk (1 KiB)
+constexpr int MAX_PLAN_CHUNKS = 16;       // chunks per page (2048 segments); beyond: generic kernel
+constexpr int PLAN_SEG_MAX_BYTES = 6144;  // payload bytes of one bit-packed segment
+
+constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
+constexpr uint32_t PLAN_F_FALLBACK = 2u;  // plan not usable (pool exhausted, too many segments): generic kernel
+
+// Everything the expansion kernel needs to know about a page (it does not read the descriptor).
+struct RlePagePlan {
+  int32_t status;       // status of the header walk (PQD_OK, or the failure met at output index n_out)
+  uint32_t n_out;       // values covered by the segments
+  uint32_t consumed;    // stream bytes consumed (bytes_consumed of the result)
+  uint32_t nseg;
+  uint32_t w;           // bit width of the ids
+  uint32_t flags;       // PLAN_F_*
+  uint32_t nchunks;
+  uint32_t stream_end;  // offset from `data` where the hybrid stream ends
+  uint64_t data;        // copies of the descriptor's pointers
+  uint64_t out;
+  uint64_t dict;
+  uint32_t dict_len;
+  uint32_t data_len;
+  uint32_t chunk[MAX_PLAN_CHUNKS];  // pool chunk numbers, in order (chunk[0] == page number)
+};
+static_assert(sizeof(RlePagePlan) == 128, "plan record is 128 bytes");
+
+}  // namespace pqd

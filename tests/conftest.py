@@ -18,3 +18,11 @@ def orc():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(params=["generic", "sliced"])
+def dict_path(request, monkeypatch):
+    """Runs a test once per dictionary-page kernel path of the library (PQD_DICT_PATH is read on
+    every call; monkeypatch.setenv reaches the C library's getenv through os.putenv)."""
+    monkeypatch.setenv("PQD_DICT_PATH", request.param)
+    return request.param

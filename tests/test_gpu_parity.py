@@ -179,7 +179,7 @@ def test_rle_many_tiny_runs(gpu, orc):
 
 # ------------------------------------------------------------------------------- dictionary
 @pytest.mark.parametrize("dtype", [np.int32, np.int64, np.float32, np.float64])
-def test_dictionary_pages(gpu, orc, dtype):
+def test_dictionary_pages(gpu, orc, dtype, dict_path):
     import parquet_java_amd as pq
     rng = np.random.default_rng(11)
     elem = np.dtype(dtype).itemsize

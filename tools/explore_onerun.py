@@ -34,4 +34,5 @@ def main():
         d3 = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(pg))).to(dev)
         ms = timeit(lambda: pq.decode_pages_dev(d3.data_ptr(), d_res.data_ptr(), pages, pq.ENC_RLE_DICTIONARY, elem, stream))
         print(f"one-run pages, dict elem={elem}: {ms*1e3:.1f} us  {(pages*page_len + pages*V*elem)/ms/1e6:.1f} GB/s")
-main()
+if __name__ == "__main__":
+    main()

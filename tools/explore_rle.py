@@ -65,4 +65,5 @@ def main():
                 alg = nv * w // 8 + nv * 4
                 print(f"raw unpack w={w:2d} n={nv}: {ms*1e3:8.1f} us  {alg/ms/1e6:8.1f} GB/s alg", flush=True)
         del blob, ids, dictionary, out
-main()
+if __name__ == "__main__":
+    main()

@@ -112,7 +112,7 @@ __device__ __forceinline__ void prefetch_slice(const T* dict, uint32_t s0, T* bu
   }
 }
 
-template <typename T, int THREADS, int R, int S>
+template <typename T, int THREADS, int R, int S, int ROT = 0, int SKEL = 0>
 __global__ __launch_bounds__(THREADS) void k_slices_db(const uint16_t* __restrict__ ids, const T* __restrict__ dict,
                                                        uint32_t dict_len, T* __restrict__ out, size_t n) {
   extern __shared__ u32x4 lds4[];
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(THREADS) void k_slices_db(const uint16_t* __restric
   const size_t batch = (size_t)THREADS * R;
   const uint32_t P = dict_len / S;
   uint32_t q = 0;  // pass counter; buffer q&1 holds slice q%P
-  prefetch_slice<T, THREADS, S>(dict, 0, lds);
+  const uint32_t rot = ROT ? (blockIdx.x * ROT) % P : 0;
+  prefetch_slice<T, THREADS, S>(dict, rot * S, lds);
   for (size_t b0 = (size_t)blockIdx.x * batch; b0 < n; b0 += (size_t)gridDim.x * batch) {
     uint32_t id[R];
     T v[R];
@@ -137,10 +138,12 @@ __global__ __launch_bounds__(THREADS) void k_slices_db(const uint16_t* __restric
     for (int r = 0; r < R; ++r) v[r] = 0;
     for (uint32_t s = 0; s < P; ++s, ++q) {
       __syncthreads();  // slice q landed (vmcnt(0) + barrier); everyone is done with the other buffer
-      const uint32_t nxt = (s + 1 == P) ? 0 : s + 1;
+      const uint32_t sl = (s + rot) % P;
+      const uint32_t nxt = (sl + 1 == P) ? 0 : sl + 1;
       prefetch_slice<T, THREADS, S>(dict, nxt * S, lds + (size_t)((q + 1) & 1) * S);
       const T* cur = lds + (size_t)(q & 1) * S;
-      const uint32_t s0 = s * S;
+      const uint32_t s0 = sl * S;
+      if (SKEL) continue;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         uint32_t idx = id[r] - s0;
@@ -318,6 +321,28 @@ void run(size_t n) {
     SL(1024, 32, 32768, false, 1);
   }
 
+#define SLDBX(THREADS, R, S, ROT, SKEL)                                                                          \
+  {                                                                                                              \
+    size_t lds = (size_t)2 * S * sizeof(T);                                                                      \
+    CHECK(hipFuncSetAttribute((const void*)k_slices_db<T, THREADS, R, S, ROT, SKEL>,                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    us = time_it([&] {                                                                                           \
+      hipLaunchKernelGGL((k_slices_db<T, THREADS, R, S, ROT, SKEL>), dim3(256), dim3(THREADS), lds, 0, ids, dict, \
+                         D, out, n);                                                                             \
+    });                                                                                                          \
+    if (!SKEL) check("slices dbx");                                                                              \
+    char nm[128];                                                                                                \
+    snprintf(nm, sizeof nm, "dbuf thr=%d R=%d S=%d rot=%d skeleton=%d", THREADS, R, S, ROT, SKEL);                \
+    report(nm, us);                                                                                              \
+  }
+  SLDBX(1024, 20, (65536 / sizeof(T)), 0, 0);
+  SLDBX(1024, 20, (65536 / sizeof(T)), 0, 1);
+  SLDBX(1024, 20, (65536 / sizeof(T)), 1, 0);
+  SLDBX(1024, 20, (65536 / sizeof(T)), 1, 1);
+  SLDBX(1024, 20, (32768 / sizeof(T)), 1, 1);
+  SLDBX(1024, 20, (32768 / sizeof(T)), 0, 1);
+  SLDBX(512, 20, (65536 / sizeof(T)), 0, 1);
+  SLDBX(256, 20, (65536 / sizeof(T)), 0, 1);
 #define SLDB(THREADS, R, S, WGS)                                                                                 \
   {                                                                                                              \
     size_t lds = (size_t)2 * S * sizeof(T);                                                                      \
