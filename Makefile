@@ -22,8 +22,13 @@ asm: $(SRCS) $(HDRS)
 	cd build/asm && for f in k_unpack k_rle k_rle_plan k_dict_sliced k_delta k_bss; do \
 	  $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o $$f.s ../../$(CSRC)/$$f.hip -Rpass-analysis=kernel-resource-usage 2> $$f.usage.txt; done
 
+# development build with per-phase cycle counters in the sliced dictionary kernel (load it with PQD_LIB_PATH)
+prof: $(SRCS) $(HDRS)
+	@mkdir -p build/prof
+	$(HIPCC) $(HIPFLAGS) -DPQD_PROF -shared -o build/prof/libpqdecode_hip.so $(SRCS)
+
 clean:
 	rm -rf $(PKG)/lib build
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle asm clean
+.PHONY: all oracle asm prof clean

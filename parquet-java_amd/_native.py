@@ -13,7 +13,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpqdecode_hip.so")
+LIB_PATH = os.environ.get("PQD_LIB_PATH") or os.path.join(_HERE, "lib", "libpqdecode_hip.so")  # override: development builds
 
 OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5

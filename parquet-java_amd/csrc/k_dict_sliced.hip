@@ -9,92 +9,122 @@
 //
 //   - one 1024-thread workgroup per CU walks over pages; the run plan of each page comes from
 //     k_rle_plan, so nothing here is serial;
-//   - 14 of the 16 waves hold values: a tile of up to 896*R ids is unpacked into REGISTERS from
-//     packed dwords read straight from global memory (coalesced; each lane owns units of four
-//     consecutive values);
-//   - the other 2 waves are loaders: they stream the dictionary through LDS in 64 KiB slices,
-//     double-buffered, by LDS-DMA (global_load_lds_dwordx4).  Only the loaders wait for their own
-//     memory operations at the workgroup barriers, so the value waves' loads and stores stay in
-//     flight across barriers;
+//   - a tile of up to 1024*R ids is unpacked into REGISTERS from packed dwords read straight from
+//     global memory (coalesced; each lane owns units of four consecutive values);
+//   - the dictionary streams through LDS in 64 KiB slices, double-buffered, by LDS-DMA
+//     (global_load_lds_dwordx4) issued by all 16 waves;
 //   - each pass resolves the ids that fall into the resident slice; a resolved id is replaced in
 //     place by its value;
 //   - while one page is being gathered, the next page's plan, segments and packed dwords are
-//     already being fetched, so no memory round trip is exposed between pages;
+//     already being fetched (behind passes 0 and 1), so no memory round trip is exposed between
+//     pages;
 //   - the values are stored once, 16 bytes per lane, fully coalesced.
 // HBM traffic per value: w/8 bytes of ids + ELEM bytes out; the slices are L2 traffic
 // (dictionary bytes per tile, i.e. a few bytes per value).  Small dictionaries (one slice) stay
-// resident across pages.  Dictionaries too large to sweep fall back to a direct gather.
+// resident across pages.  Pages this kernel is not made for (more than SEG_CHUNK segments, a
+// dictionary too large to sweep) are flagged by the plan kernel and left to the generic kernel.
 #include "pqd_device.hpp"
+#ifdef PQD_PROF
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 #include "pqd_kernels.hpp"
 #include "pqd_rle_plan.hpp"
 
 namespace pqd {
 
 constexpr int DS_THREADS = 1024;
-constexpr int DS_LOADER_WAVES = 2;
-constexpr int DS_VALUE_THREADS = DS_THREADS - 64 * DS_LOADER_WAVES;  // 896
-constexpr int DS_SLICE_BYTES = 64 * 1024;
-constexpr int DS_MAX_PASSES = 32;
-constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;  // one segment chunk, 1 KiB
+constexpr int DS_WAVES = DS_THREADS / 64;
+constexpr int DS_R = DS_TILE_VALUES / DS_THREADS;  // values per lane per tile
+constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;         // one page's segments
+constexpr int DS_PLAN_BYTES = 64;
 
-constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;               // two segment-chunk buffers
-constexpr int DS_OFF_PLANS = DS_OFF_SEGS + 2 * DS_SEG_BYTES;  // two plan records
-constexpr int DS_OFF_STATE = DS_OFF_PLANS + 2 * 128;
+constexpr int DS_NWP = 3;  // packed dwords kept per unit (enough for widths <= 16; wider: value by value)
+
+constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;               // three segment buffers
+constexpr int DS_OFF_PLANS = DS_OFF_SEGS + 3 * DS_SEG_BYTES;  // three plan records
+constexpr int DS_OFF_STATE = DS_OFF_PLANS + 4 * DS_PLAN_BYTES;
 constexpr int DS_LDS_BYTES = DS_OFF_STATE + 64;
 static_assert(DS_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(DS_OFF_STATE % 16 == 0, "state block alignment");
+static_assert(sizeof(RlePagePlan) == DS_PLAN_BYTES, "plan record size");
+static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag bit per value");
 
 #define PQD_GLOBAL __attribute__((address_space(1)))
 #define PQD_LDS __attribute__((address_space(3)))
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// Build with -DPQD_PROF for per-phase cycle counts (development only; see the Makefile's prof target).
+#ifdef PQD_PROF
+#define PROF_INIT uint64_t pt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t pl_ = __builtin_readcyclecounter();
+#define PROF(i) { const uint64_t n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pl_; pl_ = n_; }
+#define PROF_PARAM , uint64_t* prof
+#define PROF_ARG , g_prof
+#define PROF_FN_PARAM , uint64_t (&pt_)[12], uint64_t& pl_
+#define PROF_FN_ARG , pt_, pl_
+#else
+#define PROF_INIT
+#define PROF(i)
+#define PROF_PARAM
+#define PROF_ARG
+#define PROF_FN_PARAM
+#define PROF_FN_ARG
+#endif
 
 struct DsShared {
-  uint32_t oob_at;
-  uint32_t pad[3];
+  uint32_t oob_at[3];  // first out-of-range id of the page in plan buffer 0 / 1 / 2
+  uint32_t pad;
   uint32_t dummy[4];  // what lanes without a lookup read (never written after the prologue)
 };
 
-// Workgroup barrier that does not drain the value waves' global loads and stores: LDS traffic is
-// waited for by everybody, vector-memory traffic (the LDS-DMA) only by the loader waves.
-__device__ __forceinline__ void wg_barrier(bool loader) {
-  if (loader)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes at gbase + goff land at LDS byte address
+// lds_base + 16*l (gbase and lds_base wave-uniform).  Issued through inline assembly on purpose:
+// the compiler orders every LDS-DMA it knows of against all later LDS accesses and LDS-DMAs with a
+// full s_waitcnt vmcnt(0), which serialises the DMA instructions of a wave and stalls the lookups
+// behind the slice being prefetched into the OTHER buffer.  Completion is awaited explicitly in
+// wg_barrier().
+__device__ __forceinline__ void dma16(const void* gbase, uint32_t goff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(goff), "s"(gbase)
+               : "memory");
 }
 
-// Loader waves: fill one slice buffer by LDS-DMA; a wave instruction moves 64 x 16 bytes to
-// consecutive LDS addresses.  `bytes` is the valid length of the slice.
-__device__ __forceinline__ void load_slice(const uint8_t* slice_src, uint32_t bytes, uint8_t* buf, uint32_t lwave,
+// Workgroup barrier that also waits for all of this wave's outstanding memory operations, the
+// LDS-DMA included (the counters are in issue order).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same, but the wave's N most recent memory operations may stay in flight.
+template <int N>
+__device__ __forceinline__ void wg_barrier_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// Barrier for LDS traffic only.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Fills one slice buffer; `bytes` is the valid length of the slice (a multiple of the element
+// size; the dictionary is 16-byte aligned, the tail piece may read up to 15 bytes past it inside
+// the same 16-byte block).
+__device__ __forceinline__ void load_slice(const uint8_t* slice_src, uint32_t bytes, uint32_t lds_buf, uint32_t wave,
                                            uint32_t lane) {
   const uint32_t pieces = (bytes + 15) >> 4;
-#pragma unroll 4
-  for (int i = 0; i < DS_SLICE_BYTES / 16 / (64 * DS_LOADER_WAVES); ++i) {
-    const uint32_t piece0 = ((uint32_t)i * DS_LOADER_WAVES + lwave) * 64;  // wave-uniform
-    if (piece0 >= pieces) break;
-    if (piece0 + lane < pieces)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(slice_src + (size_t)(piece0 + lane) * 16),
-                                       (lds_void_t*)(buf + (size_t)piece0 * 16), 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < (int)(DS_SLICE_BYTES / 16 / DS_THREADS); ++i) {
+    const uint32_t piece0 = ((uint32_t)i * DS_WAVES + wave) * 64;  // wave-uniform
+    if (piece0 + lane < pieces) dma16(slice_src, (piece0 + lane) * 16, uni(lds_buf + piece0 * 16));
   }
 }
 
-// Loader waves: LDS-DMA of a page's plan record (128 B) and first segment chunk (1 KiB; chunk 0
-// of page p is pool chunk p).
+// A page's segments (1 KiB per wave, starting with wave 0; the segments of page p are pool chunk
+// p) and plan record (the next wave) into the LDS buffers `seg_buf` / `plan_buf` (LDS byte
+// addresses).
 __device__ __forceinline__ void fetch_plan_async(const RlePagePlan* plans, const RleSeg* pool, uint32_t page,
-                                                 uint8_t* seg_buf, uint8_t* plan_buf, uint32_t lwave, uint32_t lane) {
-  if (lwave == 0) {
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(pool + (size_t)page * SEG_CHUNK);
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (size_t)lane * 16), (lds_void_t*)seg_buf, 16, 0, 0);
-  } else if (lwave == 1) {
-    if (lane < 8) {
-      const uint8_t* src = reinterpret_cast<const uint8_t*>(plans + page);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + (size_t)lane * 16), (lds_void_t*)plan_buf, 16, 0, 0);
-    }
+                                                 uint32_t seg_buf, uint32_t plan_buf, uint32_t wave, uint32_t lane) {
+  if (wave < (uint32_t)(DS_SEG_BYTES / 1024)) {
+    dma16(pool + (size_t)page * SEG_CHUNK, wave * 1024 + lane * 16, uni(seg_buf + wave * 1024));
+  } else if (wave == (uint32_t)(DS_SEG_BYTES / 1024)) {
+    if (lane < (uint32_t)(DS_PLAN_BYTES / 16)) dma16(plans + page, lane * 16, uni(plan_buf));
   }
 }
-
-__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // Page constants, read from the plan record in LDS and held in scalar registers.
 struct PageHead {
@@ -106,8 +136,7 @@ struct PageHead {
   uint32_t n_out, w, nseg, flags;
 };
 
-__device__ __forceinline__ PageHead read_head(const uint8_t* plan_buf) {
-  const PQD_LDS RlePagePlan* pl = (const PQD_LDS RlePagePlan*)(plan_buf);
+__device__ __forceinline__ PageHead read_head(const PQD_LDS RlePagePlan* pl) {
   PageHead h;
   const uint32_t dlo = uni((uint32_t)pl->data), dhi = uni((uint32_t)(pl->data >> 32));
   const uint64_t data = ((uint64_t)dhi << 32) | dlo;
@@ -129,7 +158,7 @@ __device__ __forceinline__ PageHead read_head(const uint8_t* plan_buf) {
 template <int NW>
 struct UnitRaw {
   uint32_t d[NW];
-  uint32_t meta;  // bits 0..4: bit offset inside d[0]; bits 8..9: kind
+  uint32_t meta;  // bits 0..4: bit offset inside d[0]; bits 8..9: kind; bits 16..: segment index
 };
 constexpr uint32_t UK_NONE = 0, UK_PACKED = 1, UK_RLE = 2, UK_SLOW = 3;
 
@@ -137,60 +166,60 @@ __device__ __forceinline__ uint32_t seg_start(const PQD_LDS RleSeg* cs, uint32_t
   return cs[i].start_kind & SEG_START_MASK;
 }
 
-// For every unit of the tile starting at t0 that lies in the chunk's value range [lo, hi): find
-// its segment (binary search in LDS) and ISSUE the global loads of its packed dwords.  Nothing
-// waits on the loads here, so all units' loads are in flight together (and, when this is called
-// for the next page during a sweep, they complete behind the sweep).  NW = dwords kept per unit:
-// units of wider ids (ceil((31 + 4w) / 32) > NW) are marked for the value-by-value path.
+// For every unit of the page's values [0, t1): find its segment and ISSUE the global loads of its packed
+// dwords.  Nothing waits on the loads here, so all units' loads are in flight together (and, when
+// this is called for the next page during a sweep, they complete behind the sweep).  NW = dwords
+// kept per unit: units of wider ids (ceil((31 + 4w) / 32) > NW) are marked for the value-by-value
+// path, as are units that straddle segments or lie in a segment cut short by the end of the stream.
 template <int UNITS, int NW>
-__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t chunk_end,
-                                             uint32_t t0, uint32_t lo, uint32_t hi, const PageHead& h, uint32_t vt,
-                                             UnitRaw<NW> (&raw)[UNITS]) {
+__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t t1, const PageHead& h,
+                                             uint32_t tid, UnitRaw<NW> (&raw)[UNITS] PROF_FN_PARAM) {
+  constexpr uint32_t t0 = 0;
   const uint32_t nw = (62u + 4u * h.w) >> 5;
-  uint32_t s = 0;
+  // segment of every unit: a branch-free binary search, the units' steps interleaved so that
+  // each step is one LDS round trip for all of them
+  uint32_t seg[UNITS];
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) seg[k] = 0;
+#pragma unroll
+  for (uint32_t half = SEG_CHUNK / 2; half; half >>= 1) {
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+      const uint32_t m = seg[k] + half;
+      const uint32_t st = seg_start(cs, m < count ? m : count - 1);
+      seg[k] = (m < count && st <= g0) ? m : seg[k];
+    }
+  }
+  PROF(10)
+  // Classification and addresses are plain arithmetic and the loads are issued by every lane for
+  // every unit (units without packed dwords read the first dwords of the page): a load whose
+  // destination register is also written on another control-flow path would have to be waited
+  // for on the spot, one memory round trip per unit.
+  uint32_t wi[UNITS];
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
-    raw[k].meta = UK_NONE << 8;
-#pragma unroll
-    for (int j = 0; j < NW; ++j) raw[k].d[j] = 0;
-    const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_VALUE_THREADS + vt);
-    if (g0 + 4 <= lo || g0 >= hi) continue;
-    const uint32_t l0 = g0 > lo ? g0 : lo;
-    uint32_t a = s, b = count;  // start[a] <= l0 < start[b]
-    while (b - a > 1) {
-      const uint32_t m = (a + b) >> 1;
-      if (seg_start(cs, m) <= l0)
-        a = m;
-      else
-        b = m;
-    }
-    s = a;
-    const uint32_t sk = cs[s].start_kind;
+    const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+    const uint32_t sg = seg[k];
+    const uint32_t sk = cs[sg].start_kind, src = cs[sg].src;
     const uint32_t s_begin = sk & SEG_START_MASK;
-    const uint32_t s_end = s + 1 < count ? seg_start(cs, s + 1) : chunk_end;
-    // widths whose units need more than NW dwords take the value-by-value path
-    if (g0 >= lo && g0 + 4 <= hi && g0 + 4 <= s_end && !(sk & SEG_PARTIAL_BIT) && (nw <= (uint32_t)NW || !(sk & SEG_PACKED_BIT))) {
-      const uint32_t src = cs[s].src;
-      if (sk & SEG_PACKED_BIT) {
-        // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
-        const uint32_t byte0 = h.in_off + src;
-        const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - s_begin) * h.w;
-        const uint32_t wi = (byte0 >> 2) + (bitrel >> 5);
-        raw[k].meta = (bitrel & 31u) | (UK_PACKED << 8);
+    const uint32_t s_end = sg + 1 < count ? seg_start(cs, sg + 1) : h.n_out;
+    const bool is_packed = (sk & SEG_PACKED_BIT) != 0;
+    const bool whole = g0 + 4 <= t1 && g0 + 4 <= s_end && !(sk & SEG_PARTIAL_BIT) && (nw <= (uint32_t)NW || !is_packed);
+    // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
+    const uint32_t byte0 = h.in_off + src;
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - s_begin) * h.w;
+    const uint32_t kind = g0 >= t1 ? UK_NONE : (!whole ? UK_SLOW : (is_packed ? UK_PACKED : UK_RLE));
+    wi[k] = kind == UK_PACKED ? (byte0 >> 2) + (bitrel >> 5) : 0u;
+    raw[k].meta = (kind == UK_PACKED ? (bitrel & 31u) : 0u) | (kind << 8) | (sg << 16);
+  }
+  PROF(11)
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-          if ((uint32_t)j < nw) {  // uniform
-            const uint32_t idx = wi + j < h.last_word ? wi + j : h.last_word;  // never past the page
-            raw[k].d[j] = h.words[idx];
-          }
-        }
-      } else {
-        raw[k].meta = UK_RLE << 8;
-        raw[k].d[0] = src;
-      }
-    } else {
-      raw[k].meta = UK_SLOW << 8;
-      raw[k].d[0] = s;
+  for (int k = 0; k < UNITS; ++k) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const uint32_t idx = wi[k] + j < h.last_word ? wi[k] + j : h.last_word;  // never past the page
+      raw[k].d[j] = h.words[idx];
     }
   }
 }
@@ -201,330 +230,302 @@ __device__ __forceinline__ uint32_t guarded_word(const PageHead& h, uint32_t i) 
   return 0u;  // at or past the end of the stream
 }
 
-// Turns the fetched dwords into ids.  Units that straddle segments (or sit in a segment cut short
-// by the end of the stream) are done value by value with loads of their own.
+// Turns the fetched dwords into ids (values at or beyond t1 stay 0).
 template <int UNITS, int NW>
-__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t t0, uint32_t lo,
-                                        uint32_t hi, const PageHead& h, uint32_t vt, const UnitRaw<NW> (&raw)[UNITS],
-                                        uint32_t (&id)[UNITS * 4]) {
+__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t t1, const PageHead& h,
+                                        uint32_t tid, const UnitRaw<NW> (&raw)[UNITS], uint32_t (&id)[UNITS * 4]) {
+  constexpr uint32_t t0 = 0;
   const uint32_t mask = mask32(h.w);
+  bool any_slow = false;
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
-    const uint32_t kind = raw[k].meta >> 8;
-    if (kind == UK_PACKED) {
-      Window5 wnd = {raw[k].d[0], NW > 1 ? raw[k].d[NW > 1 ? 1 : 0] : 0u, NW > 2 ? raw[k].d[NW > 2 ? 2 : 0] : 0u,
-                     NW > 3 ? raw[k].d[NW > 3 ? 3 : 0] : 0u, NW > 4 ? raw[k].d[NW > 4 ? 4 : 0] : 0u};
-      wnd.shr(raw[k].meta & 31u);
-      id[4 * k] = wnd.d0 & mask;
-      wnd.drop(h.w);
-      id[4 * k + 1] = wnd.d0 & mask;
-      wnd.drop(h.w);
-      id[4 * k + 2] = wnd.d0 & mask;
-      wnd.drop(h.w);
-      id[4 * k + 3] = wnd.d0 & mask;
-    } else if (kind == UK_RLE) {
-      id[4 * k] = id[4 * k + 1] = id[4 * k + 2] = id[4 * k + 3] = raw[k].d[0];
-    } else if (kind == UK_SLOW) {
-      const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_VALUE_THREADS + vt);
-      uint32_t t = raw[k].d[0];
+    const uint32_t kind = (raw[k].meta >> 8) & 3u;
+    Window5 wnd = {raw[k].d[0], NW > 1 ? raw[k].d[NW > 1 ? 1 : 0] : 0u, NW > 2 ? raw[k].d[NW > 2 ? 2 : 0] : 0u,
+                   NW > 3 ? raw[k].d[NW > 3 ? 3 : 0] : 0u, NW > 4 ? raw[k].d[NW > 4 ? 4 : 0] : 0u};
+    wnd.shr(raw[k].meta & 31u);
+    const uint32_t a0 = wnd.d0 & mask;
+    wnd.drop(h.w);
+    const uint32_t a1 = wnd.d0 & mask;
+    wnd.drop(h.w);
+    const uint32_t a2 = wnd.d0 & mask;
+    wnd.drop(h.w);
+    const uint32_t a3 = wnd.d0 & mask;
+    const bool packed = kind == UK_PACKED;
+    const uint32_t other = kind == UK_RLE ? cs[raw[k].meta >> 16].src : 0u;  // the repeated value of an RLE run
+    id[4 * k] = packed ? a0 : other;
+    id[4 * k + 1] = packed ? a1 : other;
+    id[4 * k + 2] = packed ? a2 : other;
+    id[4 * k + 3] = packed ? a3 : other;
+    any_slow |= kind == UK_SLOW;
+  }
+  if (any_slow) {  // rare: run boundaries that are not multiples of four, truncated final runs, wide ids
+#pragma unroll 1
+    for (int k = 0; k < UNITS; ++k) {
+      uint32_t meta = 0;
+#pragma unroll
+      for (int kk = 0; kk < UNITS; ++kk) meta = kk == k ? raw[kk].meta : meta;  // k is not a compile-time constant
+      if (((meta >> 8) & 3u) != UK_SLOW) continue;
+      const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+      uint32_t t = meta >> 16;
+      uint32_t v[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t g = g0 + j;
-        if (g < lo || g >= hi) continue;
+        if (g >= t1) continue;
         while (t + 1 < count && seg_start(cs, t + 1) <= g) ++t;
         const uint32_t tk = cs[t].start_kind, src = cs[t].src;
         if (tk & SEG_PACKED_BIT) {
           const uint32_t byte0 = h.in_off + src;
           const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk & SEG_START_MASK)) * h.w;
           const uint32_t wi = (byte0 >> 2) + (bitrel >> 5);
-          id[4 * k + j] = funnel_shr(guarded_word(h, wi), guarded_word(h, wi + 1), bitrel & 31u) & mask;
+          v[j] = funnel_shr(guarded_word(h, wi), guarded_word(h, wi + 1), bitrel & 31u) & mask;
         } else {
-          id[4 * k + j] = src;
+          v[j] = src;
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < UNITS; ++kk) {
+        if (kk == k) {
+          id[4 * kk] = v[0];
+          id[4 * kk + 1] = v[1];
+          id[4 * kk + 2] = v[2];
+          id[4 * kk + 3] = v[3];
         }
       }
     }
   }
 }
 
-template <int ELEM, int R>
+template <int ELEM>
 __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_result* __restrict__ results,
                                                                   const RlePagePlan* __restrict__ plans,
-                                                                  const RleSeg* __restrict__ pool, uint32_t n_pages) {
+                                                                  const RleSeg* __restrict__ pool, uint32_t n_pages PROF_PARAM) {
   extern __shared__ u32x4 lds4[];
   uint8_t* lds = reinterpret_cast<uint8_t*>(lds4);
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(PQD_LDS uint8_t*)lds;  // LDS byte address of the dynamic block
 
+  constexpr int R = DS_R;
   constexpr int UNITS = R / 4;
-  constexpr int NWP = 3;  // dwords per unit kept for the prefetched page (enough for widths <= 16)
-  constexpr uint32_t TILE = DS_VALUE_THREADS * R;
+  constexpr int NWP = DS_NWP;
   constexpr uint32_t S = DS_SLICE_BYTES / ELEM;  // dictionary entries per slice
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63u;
-  const bool loader = wave >= (uint32_t)(DS_THREADS / 64 - DS_LOADER_WAVES);  // wave-uniform role
-  const uint32_t lwave = wave - (DS_THREADS / 64 - DS_LOADER_WAVES);
-  const uint32_t vt = tid;  // value-thread index (only meaningful for value waves)
 
-  // which slice each LDS buffer holds (uniform over the workgroup; both roles track it)
-  uint64_t tag_dict0 = 0, tag_dict1 = 0;
+  // which slice each LDS buffer holds (uniform over the workgroup)
+  uint64_t tag_dict = 0;
   uint32_t tag_s0 = ~0u, tag_s1 = ~0u;
   uint32_t q = 0;  // pass counter: pass q uses buffer q & 1
 
   uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
-  uint32_t pb = 0;  // which plan / segment buffer holds the current page
-  if (loader) fetch_plan_async(plans, pool, page, lds + DS_OFF_SEGS, lds + DS_OFF_PLANS, lwave, lane);
-  if (tid == 0) sh->oob_at = ~0u;
+  const uint32_t stride = gridDim.x;
+  // Plan / segment buffers form a ring of three: the current page, the next one (its packed dwords
+  // are fetched while the current page is gathered) and the one after (its plan is on its way).
+  uint32_t pb = 0;
+  fetch_plan_async(plans, pool, page, lds0 + DS_OFF_SEGS, lds0 + DS_OFF_PLANS, wave, lane);
+  if (page + stride < n_pages)
+    fetch_plan_async(plans, pool, page + stride, lds0 + DS_OFF_SEGS + DS_SEG_BYTES, lds0 + DS_OFF_PLANS + DS_PLAN_BYTES, wave,
+                     lane);
+  if (tid < 3) sh->oob_at[tid] = ~0u;
   if (tid < 4) sh->dummy[tid] = 0;
-  wg_barrier(loader);
+  wg_barrier();
 
-  UnitRaw<NWP> raw[UNITS];
-  bool have_raw = false;  // raw[] already holds the first tile of the current page
+  // a head whose loads all hit one valid dword, for when there is no page to prefetch
+  PageHead idle;
+  idle.words = (const PQD_GLOBAL uint32_t*)plans;
+  idle.in_off = idle.last_word = idle.full_words = idle.tail_mask = 0;
+  idle.n_out = idle.w = idle.flags = 0;
+  idle.nseg = 1;
+
+  UnitRaw<NWP> raw[UNITS];  // packed dwords of the page about to be decoded
+  PROF_INIT
+  {
+    const PageHead h0 = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS));
+    const bool ok = !(h0.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) && h0.n_out > 0;
+    const PageHead& f = ok ? h0 : idle;
+    locate_fetch<UNITS, NWP>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), f.nseg, f.n_out, f, tid, raw PROF_FN_ARG);
+  }
 
   for (;;) {
-    const uint8_t* plan_buf = lds + DS_OFF_PLANS + pb * 128;
+    const uint32_t nb = pb == 2 ? 0u : pb + 1, nnb = nb == 2 ? 0u : nb + 1;
     const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + pb * DS_SEG_BYTES);
-    const PQD_LDS RlePagePlan* lpl = (const PQD_LDS RlePagePlan*)(plan_buf);
-    const PageHead h = read_head(plan_buf);
+    const PQD_LDS RlePagePlan* lpl = (const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + pb * DS_PLAN_BYTES);
+    const PageHead h = read_head(lpl);
     const bool skip = (h.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) != 0;
-    const uint32_t n_out = skip ? 0u : h.n_out, nseg = h.nseg;
+    const uint32_t n_out = skip ? 0u : h.n_out;  // at most DS_TILE_VALUES (the plan kernel sees to it)
     const uint32_t dict_len = uni(lpl->dict_len);
     const uint64_t dict_addr = ((uint64_t)uni((uint32_t)(lpl->dict >> 32)) << 32) | uni((uint32_t)lpl->dict);
     const uint64_t out_addr = ((uint64_t)uni((uint32_t)(lpl->out >> 32)) << 32) | uni((uint32_t)lpl->out);
     const int32_t page_status = (int32_t)uni((uint32_t)lpl->status);
     const uint32_t page_consumed = uni(lpl->consumed);
-    const uint32_t next_page = page + gridDim.x;
+    const uint32_t next_page = page + stride;
     const bool has_next = next_page < n_pages;
-    bool next_fetched = false, next_raw = false;
+    const uint32_t P = n_out ? (dict_len + S - 1) / S : 0u;
+    const uint8_t* dict_bytes = reinterpret_cast<const uint8_t*>(dict_addr);
+    if (n_out && dict_addr != tag_dict) {  // another dictionary: nothing resident is of use
+      tag_dict = dict_addr;
+      tag_s0 = tag_s1 = ~0u;
+    }
+    PROF(0)
 
-    const uint32_t P = (dict_len + S - 1) / S;
-    // chunk 0 is in LDS; later chunks replace it in the same buffer (the cursor only moves forward)
-    uint32_t chunk_i = 0, loaded_chunk = 0;
-    uint32_t count = nseg < (uint32_t)SEG_CHUNK ? nseg : (uint32_t)SEG_CHUNK;
-    uint32_t chunk_end = n_out;
-    if (nseg > (uint32_t)SEG_CHUNK && !skip)
-      chunk_end = uni(((const PQD_GLOBAL RleSeg*)pool)[(size_t)lpl->chunk[1] * SEG_CHUNK].start_kind) & SEG_START_MASK;
+    // ---- 1. ids into registers (their packed dwords were requested one page ago)
+    uint32_t id[R];
+    extract<UNITS, NWP>(cs, skip ? 1u : h.nseg, n_out, h, tid, raw, id);
+    PROF(1)
 
-    for (uint32_t t0 = 0; t0 < n_out; t0 += TILE) {
-      const uint32_t t1 = (n_out - t0 > TILE) ? t0 + TILE : n_out;
-      const bool last_tile = t1 == n_out;
-      uint32_t id[R];
+    // ---- 2. prefetch: the plan of the page after the next, the packed dwords of the next page.
+    // The loads are issued unconditionally (from a harmless address when there is nothing to
+    // fetch) so that exactly NWP * UNITS of them are this wave's most recent memory operations
+    // when it reaches the first barrier of the sweep.
+    if (next_page + stride < n_pages && next_page + stride >= next_page)
+      fetch_plan_async(plans, pool, next_page + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES,
+                       lds0 + DS_OFF_PLANS + nnb * DS_PLAN_BYTES, wave, lane);
+    {
+      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES));
+      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) && nh.n_out > 0;
+      const PageHead& f = ok ? nh : idle;
+      locate_fetch<UNITS, NWP>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), f.nseg, f.n_out, f, tid, raw PROF_FN_ARG);
+    }
+    PROF(8)
+
+    // ---- 3. ids beyond the dictionary: flag the first one, never look them up.
+    // `done` has one bit per register slot: set = nothing (more) to look up for it.
+    uint32_t done = 0;
+    {
+      uint32_t bad = ~0u;
 #pragma unroll
-      for (int r = 0; r < R; ++r) id[r] = 0;
-
-      // ---- 1. ids of [t0, t1) into registers, one segment chunk at a time
-      for (;;) {
-        if (loaded_chunk != chunk_i) {
-          wg_barrier(loader);  // earlier readers of the segment buffer are done
-          const uint32_t first = chunk_i * SEG_CHUNK;
-          count = nseg - first < (uint32_t)SEG_CHUNK ? nseg - first : (uint32_t)SEG_CHUNK;
-          const PQD_GLOBAL RleSeg* src = (const PQD_GLOBAL RleSeg*)pool + (size_t)lpl->chunk[chunk_i] * SEG_CHUNK;
-          PQD_LDS RleSeg* dst = (PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + pb * DS_SEG_BYTES);
-          if (tid < count) *(PQD_LDS uint64_t*)(dst + tid) = *(const PQD_GLOBAL uint64_t*)(src + tid);
-          chunk_end = n_out;
-          if (first + count < nseg)
-            chunk_end = uni(((const PQD_GLOBAL RleSeg*)pool)[(size_t)lpl->chunk[chunk_i + 1] * SEG_CHUNK].start_kind) &
-                        SEG_START_MASK;
-          loaded_chunk = chunk_i;
-          have_raw = false;
-          wg_barrier(loader);
+      for (int k = UNITS - 1; k >= 0; --k) {
+        const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          const bool live = g0 + j < n_out;
+          const bool over = id[4 * k + j] >= dict_len;
+          bad = (live && over) ? g0 + j : bad;
+          done |= (!live || over) ? (1u << (4 * k + j)) : 0u;
+          id[4 * k + j] = (!live || over) ? 0u : id[4 * k + j];
         }
-        const uint32_t cv0 = seg_start(cs, 0);
-        const uint32_t lo = cv0 > t0 ? cv0 : t0, hi = chunk_end < t1 ? chunk_end : t1;
-        if (lo < hi && !loader) {
-          if (!have_raw) locate_fetch<UNITS, NWP>(cs, count, chunk_end, t0, lo, hi, h, vt, raw);
-          extract<UNITS, NWP>(cs, count, t0, lo, hi, h, vt, raw, id);
-        }
-        have_raw = false;
-        if (chunk_end >= t1) break;
-        ++chunk_i;
       }
+      if (bad != ~0u) atomicMin(&sh->oob_at[pb], bad);
+    }
+    PROF(2)
 
-      // ---- 2. ids beyond the dictionary: flag the first one, never look them up.
-      // `done` has one bit per register slot: set = nothing (more) to look up for it.
-      uint32_t done = 0;
-      if (!loader) {
-        uint32_t bad = ~0u;
+    // ---- 4. gather.  id[r] is replaced IN PLACE by the low word of its value once its slice has
+    // come by (vhi[r] receives the high word of 8-byte values).
+    uint32_t vhi[ELEM == 8 ? R : 1];
+    if (ELEM == 8) {
 #pragma unroll
-        for (int k = UNITS - 1; k >= 0; --k) {
-          const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_VALUE_THREADS + vt);
+      for (int r = 0; r < R; ++r) vhi[ELEM == 8 ? r : 0] = 0;
+    }
+    bool prefetch_only = true;  // this wave's memory operations since the last barrier: the prefetch loads alone
+    for (uint32_t s = 0; s < P; ++s, ++q) {
+      const uint32_t curb = q & 1u;
+      // the slice this pass needs, if no earlier pass prefetched it
+      if ((curb ? tag_s1 : tag_s0) != s) {
+        wg_barrier();  // nobody still reads this buffer
+        const uint32_t n_here = dict_len - s * S < S ? dict_len - s * S : S;
+        load_slice(dict_bytes + (size_t)s * DS_SLICE_BYTES, n_here * ELEM, lds0 + curb * DS_SLICE_BYTES, wave, lane);
+        if (curb)
+          tag_s1 = s;
+        else
+          tag_s0 = s;
+        prefetch_only = false;
+      }
+      PROF(5)
+      // this pass's slice has landed; everybody is done with the other buffer
+      if (prefetch_only)
+        wg_barrier_keep<NWP * UNITS>();  // the prefetch loads stay in flight
+      else
+        wg_barrier();
+      prefetch_only = false;
+      PROF(3)
+      // prefetch the slice of the next pass (the next page usually uses the same dictionary)
+      {
+        const uint32_t nx = s + 1 < P ? s + 1 : 0u;
+        if ((curb ? tag_s0 : tag_s1) != nx) {
+          const uint32_t n_here = dict_len - nx * S < S ? dict_len - nx * S : S;
+          load_slice(dict_bytes + (size_t)nx * DS_SLICE_BYTES, n_here * ELEM, lds0 + (curb ^ 1u) * DS_SLICE_BYTES, wave, lane);
+          if (curb)
+            tag_s0 = nx;
+          else
+            tag_s1 = nx;
+        }
+      }
+      PROF(9)
+      const uint32_t s0 = s * S;
+      if (ELEM == 4) {
+        const PQD_LDS uint32_t* buf = (const PQD_LDS uint32_t*)(lds + curb * DS_SLICE_BYTES);
 #pragma unroll
-          for (int j = 3; j >= 0; --j) {
-            const bool live = g0 + j < t1;
-            if (live && id[4 * k + j] >= dict_len) bad = g0 + j;
-            if (!live || id[4 * k + j] >= dict_len) {
-              done |= 1u << (4 * k + j);
-              id[4 * k + j] = 0;
-            }
+        for (int r = 0; r < R; ++r) {
+          const uint32_t idx = id[r] - s0;
+          if (idx < S && !(done & (1u << r))) {
+            id[r] = buf[idx];
+            done |= 1u << r;
           }
         }
-        if (bad != ~0u) atomicMin(&sh->oob_at, bad);
-      }
-
-      // ---- 3. gather.  id[r] is replaced IN PLACE by the low word of its value once its slice has
-      // come by (vhi[r] receives the high word of 8-byte values).  The lookups of one pass are
-      // branch-free so that they overlap: lanes with nothing to fetch read one shared dummy word
-      // (a broadcast, no bank conflict).
-      uint32_t vhi[ELEM == 8 ? R : 1];
-      if (ELEM == 8) {
+      } else {
+        const PQD_LDS u32x2* buf = (const PQD_LDS u32x2*)(lds + curb * DS_SLICE_BYTES);
+        const PQD_LDS u32x2* dummy = (const PQD_LDS u32x2*)(sh->dummy);
 #pragma unroll
-        for (int r = 0; r < R; ++r) vhi[ELEM == 8 ? r : 0] = 0;
-      }
-      const bool sweep = P > 0 && (dict_addr & 15u) == 0 &&
-                         (P == 1 || (P <= (uint32_t)DS_MAX_PASSES && (uint64_t)dict_len * ELEM <= 32ull * (t1 - t0)));
-      if (sweep) {
-        const uint8_t* dict_bytes = reinterpret_cast<const uint8_t*>(dict_addr);
-        for (uint32_t s = 0; s < P; ++s, ++q) {
-          const uint32_t curb = q & 1u;
-          // the slice this pass needs, if no earlier pass prefetched it
-          {
-            const uint64_t td = curb ? tag_dict1 : tag_dict0;
-            const uint32_t ts = curb ? tag_s1 : tag_s0;
-            if (td != dict_addr || ts != s) {
-              wg_barrier(loader);  // nobody still reads this buffer
-              const uint32_t n_here = dict_len - s * S < S ? dict_len - s * S : S;
-              if (loader)
-                load_slice(dict_bytes + (size_t)s * DS_SLICE_BYTES, n_here * ELEM, lds + curb * DS_SLICE_BYTES, lwave, lane);
-              if (curb) {
-                tag_dict1 = dict_addr;
-                tag_s1 = s;
-              } else {
-                tag_dict0 = dict_addr;
-                tag_s0 = s;
-              }
-            }
-          }
-          wg_barrier(loader);  // the loaders' DMA has landed; everybody is done with the other buffer
-          // prefetch the slice of the next pass (the next tile / page usually uses the same dictionary)
-          {
-            const uint32_t nx = s + 1 < P ? s + 1 : 0u;
-            const uint64_t td = curb ? tag_dict0 : tag_dict1;
-            const uint32_t ts = curb ? tag_s0 : tag_s1;
-            if (td != dict_addr || ts != nx) {
-              const uint32_t n_here = dict_len - nx * S < S ? dict_len - nx * S : S;
-              if (loader)
-                load_slice(dict_bytes + (size_t)nx * DS_SLICE_BYTES, n_here * ELEM, lds + (curb ^ 1u) * DS_SLICE_BYTES, lwave,
-                           lane);
-              if (curb) {
-                tag_dict0 = dict_addr;
-                tag_s0 = nx;
-              } else {
-                tag_dict1 = dict_addr;
-                tag_s1 = nx;
-              }
-            }
-          }
-          // the next page rides behind this page's last sweep: its plan and segments are fetched
-          // during pass 0 (loaders), its packed dwords during pass 1 (value waves)
-          if (last_tile && has_next) {
-            if (s == 0) {
-              if (loader)
-                fetch_plan_async(plans, pool, next_page, lds + DS_OFF_SEGS + (pb ^ 1u) * DS_SEG_BYTES,
-                                 lds + DS_OFF_PLANS + (pb ^ 1u) * 128, lwave, lane);
-              next_fetched = true;
-            } else if (s == 1) {
-              const uint8_t* nplan = lds + DS_OFF_PLANS + (pb ^ 1u) * 128;
-              const PageHead nh = read_head(nplan);
-              if (!(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) && nh.nseg <= (uint32_t)SEG_CHUNK && nh.n_out > 0) {
-                if (!loader) {
-                  const PQD_LDS RleSeg* ncs = (const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + (pb ^ 1u) * DS_SEG_BYTES);
-                  const uint32_t nhi = nh.n_out < TILE ? nh.n_out : TILE;
-                  locate_fetch<UNITS, NWP>(ncs, nh.nseg, nh.n_out, 0u, 0u, nhi, nh, vt, raw);
-                }
-                next_raw = true;
-              }
-            }
-          }
-          if (loader) continue;
-          const uint32_t s0 = s * S;
-          if (ELEM == 4) {
-            const PQD_LDS uint32_t* buf = (const PQD_LDS uint32_t*)(lds + curb * DS_SLICE_BYTES);
-            const PQD_LDS uint32_t* dummy = (const PQD_LDS uint32_t*)(sh->dummy);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const uint32_t idx = id[r] - s0;
-              const bool hit = idx < S && !(done & (1u << r));
-              const PQD_LDS uint32_t* p = hit ? buf + idx : dummy;
-              const uint32_t t = *p;
-              id[r] = hit ? t : id[r];
-              done |= hit ? (1u << r) : 0u;
-              if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // at most 8 lookups in flight: bounds the registers
-            }
-          } else {
-            const PQD_LDS u32x2* buf = (const PQD_LDS u32x2*)(lds + curb * DS_SLICE_BYTES);
-            const PQD_LDS u32x2* dummy = (const PQD_LDS u32x2*)(sh->dummy);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const uint32_t idx = id[r] - s0;
-              const bool hit = idx < S && !(done & (1u << r));
-              const PQD_LDS u32x2* p = hit ? buf + idx : dummy;
-              const u32x2 t = *p;
-              id[r] = hit ? t.x : id[r];
-              vhi[ELEM == 8 ? r : 0] = hit ? t.y : vhi[ELEM == 8 ? r : 0];
-              done |= hit ? (1u << r) : 0u;
-              if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 lookups in flight: bounds the registers
-            }
-          }
+        for (int r = 0; r < R; ++r) {
+          const uint32_t idx = id[r] - s0;
+          const bool hit = idx < S && !(done & (1u << r));
+          const PQD_LDS u32x2* p = hit ? buf + idx : dummy;  // lanes with nothing to fetch read one shared word
+          const u32x2 t = *p;
+          id[r] = hit ? t.x : id[r];
+          vhi[ELEM == 8 ? r : 0] = hit ? t.y : vhi[ELEM == 8 ? r : 0];
+          done |= hit ? (1u << r) : 0u;
+          if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the lookups in flight, and so the registers
         }
-      } else if (!loader) {
-        // direct gather through the vector cache (huge dictionaries, or too few values to pay for a sweep)
-        if (ELEM == 4) {
-          const PQD_GLOBAL uint32_t* dict = (const PQD_GLOBAL uint32_t*)dict_addr;
+      }
+      PROF(4)
+    }
+
+    // ---- 5. store, 16 bytes per lane per instruction
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (!(done & (1u << r))) id[r] = dict[id[r]];
+    for (int k = 0; k < UNITS; ++k) {
+      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+      if (g0 >= n_out) continue;
+      if (ELEM == 4) {
+        PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
+        if (g0 + 4 <= n_out) {
+          u32x4_a4 r4 = {id[4 * k], id[4 * k + 1], id[4 * k + 2], id[4 * k + 3]};
+          *(PQD_GLOBAL u32x4_a4*)(o) = r4;
         } else {
-          const PQD_GLOBAL u32x2_a4* dict = (const PQD_GLOBAL u32x2_a4*)dict_addr;
 #pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (!(done & (1u << r))) {
-              const u32x2_a4 x = dict[id[r]];
-              id[r] = x.x;
-              vhi[ELEM == 8 ? r : 0] = x.y;
-            }
+          for (int j = 0; j < 4; ++j)
+            if (g0 + j < n_out) o[j] = id[4 * k + j];
         }
-      }
-
-      // ---- 4. store, 16 bytes per lane per instruction
-      if (!loader) {
+      } else {
+        PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)out_addr + g0;
+        if (g0 + 4 <= n_out) {
+          u32x4_a4 r0 = {id[4 * k], vhi[ELEM == 8 ? 4 * k : 0], id[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
+          u32x4_a4 r1 = {id[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], id[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
+          *(PQD_GLOBAL u32x4_a4*)(o) = r0;
+          *(PQD_GLOBAL u32x4_a4*)(o + 2) = r1;
+        } else {
 #pragma unroll
-        for (int k = 0; k < UNITS; ++k) {
-          const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_VALUE_THREADS + vt);
-          if (g0 >= t1) continue;
-          if (ELEM == 4) {
-            PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
-            if (g0 + 4 <= t1) {
-              u32x4_a4 r4 = {id[4 * k], id[4 * k + 1], id[4 * k + 2], id[4 * k + 3]};
-              *(PQD_GLOBAL u32x4_a4*)(o) = r4;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (g0 + j < t1) o[j] = id[4 * k + j];
+          for (int j = 0; j < 4; ++j)
+            if (g0 + j < n_out) {
+              u32x2_a4 x = {id[4 * k + j], vhi[ELEM == 8 ? 4 * k + j : 0]};
+              o[j] = x;
             }
-          } else {
-            PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)out_addr + g0;
-            if (g0 + 4 <= t1) {
-              u32x4_a4 r0 = {id[4 * k], vhi[ELEM == 8 ? 4 * k : 0], id[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
-              u32x4_a4 r1 = {id[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], id[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
-              *(PQD_GLOBAL u32x4_a4*)(o) = r0;
-              *(PQD_GLOBAL u32x4_a4*)(o + 2) = r1;
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (g0 + j < t1) {
-                  u32x2_a4 x = {id[4 * k + j], vhi[ELEM == 8 ? 4 * k + j : 0]};
-                  o[j] = x;
-                }
-            }
-          }
         }
       }
     }
+    PROF(6)
 
-    wg_barrier(loader);  // all atomicMin on oob_at are in; everybody is done with this page's buffers
+    // ---- 6. page end.  All atomicMin on this page's oob slot are in after the barrier; the slot is
+    // next used three pages on.  A page without a sweep has had no barrier that made sure the
+    // plan DMA issued above has landed: it takes the full one.
+    if (P == 0)
+      wg_barrier();
+    else
+      wg_barrier_lds();
     if (!skip && tid == 0) {
       pqd_page_result r;
-      const uint32_t oob = sh->oob_at;
-      sh->oob_at = ~0u;  // for the next page; the barrier below orders it before any new atomicMin
+      const uint32_t oob = sh->oob_at[pb];
+      sh->oob_at[pb] = ~0u;
       if (oob < n_out) {
         r.status = PQD_DICT_OOB;
         r.values_written = oob;
@@ -537,17 +538,38 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
       results[page] = r;
     }
     if (!has_next) break;
-    if (!next_fetched && loader)
-      fetch_plan_async(plans, pool, next_page, lds + DS_OFF_SEGS + (pb ^ 1u) * DS_SEG_BYTES,
-                       lds + DS_OFF_PLANS + (pb ^ 1u) * 128, lwave, lane);
-    wg_barrier(loader);  // the next page's plan and segments are in LDS; oob_at has been read
-    pb ^= 1u;
+    pb = nb;
     page = next_page;
-    have_raw = next_raw;
+    PROF(7)
   }
+#ifdef PQD_PROF
+  if (lane == 0 && (wave == 0 || wave == 15)) {
+    for (int i = 0; i < 12; ++i) prof[(blockIdx.x * 2 + (wave == 15)) * 12 + i] = pt_[i];
+  }
+#endif
 }
 
 static int g_cu_count = 0;
+#ifdef PQD_PROF
+static uint64_t* g_prof = nullptr;
+static void prof_report(uint32_t grid, hipStream_t stream) {
+  static const char* names[12] = {"head", "decode", "oob", "barrier", "lookup", "pre-barrier", "store", "page-end",
+                                  "loads-issue", "dma-issue", "search", "classify"};
+  hipStreamSynchronize(stream);
+  std::vector<uint64_t> h((size_t)grid * 24);
+  hipMemcpy(h.data(), g_prof, h.size() * 8, hipMemcpyDeviceToHost);
+  if (!getenv("PQD_PROF_PRINT")) return;
+  for (int role = 0; role < 2; ++role) {
+    fprintf(stderr, "[prof] wave %d, kcycles per WG:", role ? 15 : 0);
+    for (int i = 0; i < 12; ++i) {
+      double sum = 0;
+      for (uint32_t b = 0; b < grid; ++b) sum += (double)h[((size_t)b * 2 + role) * 12 + i];
+      fprintf(stderr, " %s=%.1f", names[i], sum / grid / 1e3);
+    }
+    fprintf(stderr, "\n");
+  }
+}
+#endif
 
 hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
                                     const void* pool, uint32_t n_pages, int elem, hipStream_t stream) {
@@ -566,17 +588,23 @@ hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result*
   const RlePagePlan* pp = reinterpret_cast<const RlePagePlan*>(plans);
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
   hipError_t e;
+#ifdef PQD_PROF
+  if (!g_prof && (e = hipMalloc((void**)&g_prof, 1024 * 24 * 8)) != hipSuccess) return e;
+#endif
   if (elem == 4) {
-    auto k = k_dict_pages_sliced<4, 24>;
+    auto k = k_dict_pages_sliced<4>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages PROF_ARG);
   } else {
-    auto k = k_dict_pages_sliced<8, 24>;
+    auto k = k_dict_pages_sliced<8>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages PROF_ARG);
   }
+#ifdef PQD_PROF
+  prof_report(grid, stream);
+#endif
   return hipGetLastError();
 }
 

@@ -183,12 +183,10 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
 __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* __restrict__ descs,
                                                            pqd_page_result* __restrict__ results,
                                                            RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
-                                                           uint32_t pool_chunks, uint32_t* __restrict__ pool_cursor,
                                                            uint32_t n_pages, int want_dict, int elem) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ PlanState st;
-  __shared__ uint32_t chunk_list[MAX_PLAN_CHUNKS];
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -253,7 +251,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     return;
   }
 
-  if (n_values > SEG_START_MASK) {  // segment start indices hold 30 bits: leave such pages to the generic kernel
+  // segment start indices hold 30 bits, and the sliced dictionary kernel holds a whole page in
+  // its registers: leave larger pages to the generic kernel
+  if (n_values > SEG_START_MASK || (want_dict && n_values > DS_TILE_VALUES)) {
     if (tid == 0) {
       RlePagePlan pl = {};
       pl.flags = PLAN_F_FALLBACK;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
   __syncthreads();
 
     const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
-  uint32_t nchunks = 0, nseg = 0;
+  uint32_t nseg = 0;
   bool fallback = false;
   for (;;) {
     if (st.need_round) {
@@ -306,63 +306,53 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     __syncthreads();
     const uint32_t ns = st.nstage;
     const bool done = st.done != 0;
-    if (ns == SEG_CHUNK || (done && ns > 0)) {
-      // flush the stage to a pool chunk
-      if (tid == 0) {
-        // chunk 0 of page p is pool chunk p (readable without the plan); the rest come from the shared tail
-        uint32_t slot = ~0u;
-        if (nchunks == 0) {
-          slot = page;
-        } else if (nchunks < (uint32_t)MAX_PLAN_CHUNKS) {
-          slot = n_pages + atomicAdd(pool_cursor, 1u);
-          if (slot >= pool_chunks) slot = ~0u;
-        }
-        st.chunk_slot = slot;
-        st.nstage = 0;
-      }
-      __syncthreads();
-      const uint32_t slot = st.chunk_slot;
-      if (slot == ~0u) {
-        fallback = true;
-        break;
-      }
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (size_t)slot * SEG_CHUNK);
-      for (uint32_t i = tid; i < ns * 2; i += PLAN_THREADS) dst[i] = src[i];
-      if (tid == 0) chunk_list[nchunks] = slot;
-      ++nchunks;
-      nseg += ns;
-      __syncthreads();
+    if (ns == SEG_CHUNK && !done) {  // more segments than a planned page may have
+      fallback = true;
+      break;
     }
-    if (done) break;
+    if (done) {
+      // the segments of page p are pool chunk p
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (size_t)page * SEG_CHUNK);
+      for (uint32_t i = tid; i < ns * 2; i += PLAN_THREADS) dst[i] = src[i];
+      nseg = ns;
+      break;
+    }
   }
   if (tid == 0) {
+    const uint32_t n_out = st.vals;
+    if (want_dict && !fallback) {
+      // is streaming the dictionary through LDS cheaper than a direct gather for this page?
+      const uint32_t per_slice = DS_SLICE_BYTES / (uint32_t)elem;
+      const uint32_t passes = (d.dict_len + per_slice - 1) / per_slice;
+      const uint32_t held = n_out < DS_TILE_VALUES ? n_out : DS_TILE_VALUES;
+      const bool sweepable = ((uintptr_t)d.dict & 15u) == 0 &&
+                             (passes <= 1 || (passes <= DS_MAX_PASSES && (uint64_t)d.dict_len * (uint32_t)elem <= 32ull * held));
+      if (!sweepable) fallback = true;
+    }
     RlePagePlan pl = {};
     pl.status = st.status;
-    pl.n_out = st.vals;
+    pl.n_out = n_out;
     pl.consumed = consumed_override != ~0u ? consumed_override : st.pos;
     pl.nseg = nseg;
     pl.w = w;
     pl.flags = fallback ? PLAN_F_FALLBACK : 0u;
-    pl.nchunks = nchunks;
     pl.stream_end = end;  // bytes at or past it read as zero
+    pl.data_len = d.data_len;
     pl.data = (uint64_t)(uintptr_t)d.data;
     pl.out = (uint64_t)(uintptr_t)d.out;
     pl.dict = (uint64_t)(uintptr_t)d.dict;
     pl.dict_len = d.dict_len;
-    pl.data_len = d.data_len;
-    for (uint32_t i = 0; i < nchunks; ++i) pl.chunk[i] = chunk_list[i];
     plans[page] = pl;
   }
 }
 
 hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                           uint32_t pool_chunks, uint32_t* pool_cursor, uint32_t n_pages, bool want_dict, int elem,
-                           hipStream_t stream) {
+                           uint32_t n_pages, bool want_dict, int elem, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rle_plan, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
-                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, pool_cursor,
-                     n_pages, want_dict ? 1 : 0, elem);
+                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), n_pages,
+                     want_dict ? 1 : 0, elem);
   return hipGetLastError();
 }
 

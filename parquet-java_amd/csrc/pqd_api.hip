@@ -13,6 +13,7 @@
 
 #include "../../include/pqd.h"
 #include "pqd_kernels.hpp"
+#include "pqd_rle_plan.hpp"
 
 namespace {
 
@@ -70,14 +71,13 @@ int check_device_available() {
   return PQD_OK;
 }
 
-// Device scratch of the planned RLE path: run plans, the segment pool and its allocation counter.
+// Device scratch of the planned RLE path: one run-plan record and one segment chunk per page.
 // One per (device, stream): calls on one stream are ordered, calls on different streams must not
 // share it.  Grown on demand, never shrunk, released with the process.
 struct PlanScratch {
   void* plans = nullptr;
   void* pool = nullptr;
-  uint32_t* cursor = nullptr;
-  uint32_t cap_pages = 0, cap_chunks = 0;
+  uint32_t cap_pages = 0;
 };
 std::mutex g_plan_mutex;
 std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
@@ -87,21 +87,17 @@ int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
   PQD_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(g_plan_mutex);
   PlanScratch& ps = g_plan_scratch[std::make_pair(dev, (void*)stream)];
-  const uint32_t want_chunks = n_pages * 2 + 1024;  // chunk p belongs to page p, the rest is shared
-  if (ps.cap_pages < n_pages || ps.cap_chunks < want_chunks) {
+  if (ps.cap_pages < n_pages) {
     // wait for work that may still use the old buffers, then replace them
     PQD_HIP(hipStreamSynchronize(stream));
     if (ps.plans) (void)hipFree(ps.plans);
     if (ps.pool) (void)hipFree(ps.pool);
     ps.plans = ps.pool = nullptr;
-    ps.cap_pages = ps.cap_chunks = 0;
+    ps.cap_pages = 0;
     const uint32_t pages = n_pages + n_pages / 4 + 64;
-    const uint32_t chunks = pages * 2 + 1024;
-    PQD_HIP(hipMalloc(&ps.plans, (size_t)pages * 128));
-    PQD_HIP(hipMalloc(&ps.pool, (size_t)chunks * 128 * 8));
-    if (!ps.cursor) PQD_HIP(hipMalloc((void**)&ps.cursor, 256));
+    PQD_HIP(hipMalloc(&ps.plans, (size_t)pages * sizeof(pqd::RlePagePlan)));
+    PQD_HIP(hipMalloc(&ps.pool, (size_t)pages * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
     ps.cap_pages = pages;
-    ps.cap_chunks = chunks;
   }
   *out = ps;
   return PQD_OK;
@@ -324,9 +320,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         PlanScratch ps;
         int st = plan_scratch_for(s, n_pages, &ps);
         if (st) return st;
-        PQD_HIP(hipMemsetAsync(ps.cursor, 0, 256, s));
-        PQD_HIP(pqd::launch_rle_plan(descs, results, ps.plans, ps.pool, ps.cap_chunks, ps.cursor, n_pages, true,
-                                     elem_size, s));
+        PQD_HIP(pqd::launch_rle_plan(descs, results, ps.plans, ps.pool, n_pages, true, elem_size, s));
         PQD_HIP(pqd::launch_dict_pages_sliced(descs, results, ps.plans, ps.pool, n_pages, elem_size, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, s));
       }

@@ -19,8 +19,7 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
 // header walk -> run plans (pqd_rle_plan.hpp); `plans` holds n_pages records of 128 bytes, `pool`
 // pool_chunks chunks of 128 segments of 12 bytes, `pool_cursor` a zeroed counter
 hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                           uint32_t pool_chunks, uint32_t* pool_cursor, uint32_t n_pages, bool want_dict, int elem,
-                           hipStream_t stream);
+                           uint32_t n_pages, bool want_dict, int elem, hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather
 hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
                                     const void* pool, uint32_t n_pages, int elem, hipStream_t stream);

@@ -21,14 +21,20 @@ struct RleSeg {
 constexpr uint32_t SEG_PACKED_BIT = 0x80000000u;
 constexpr uint32_t SEG_PARTIAL_BIT = 0x40000000u;
 constexpr uint32_t SEG_START_MASK = 0x3FFFFFFFu;
-constexpr int SEG_CHUNK = 128;            // segments per pool chunk (1 KiB)
-constexpr int MAX_PLAN_CHUNKS = 16;       // chunks per page (2048 segments); beyond: generic kernel
+constexpr int SEG_CHUNK = 256;            // segments a planned page may have (2 KiB of pool per page); beyond: generic kernel
 constexpr int PLAN_SEG_MAX_BYTES = 6144;  // payload bytes of one bit-packed segment
 
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
-constexpr uint32_t PLAN_F_FALLBACK = 2u;  // plan not usable (pool exhausted, too many segments): generic kernel
+constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel
+
+// Sliced dictionary gather: LDS slice size and the values one workgroup holds in registers per
+// sweep.  The plan kernel uses them to decide whether sweeping the dictionary pays for a page.
+constexpr uint32_t DS_SLICE_BYTES = 64 * 1024;
+constexpr uint32_t DS_TILE_VALUES = 1024 * 20;
+constexpr uint32_t DS_MAX_PASSES = 32;
 
 // Everything the expansion kernel needs to know about a page (it does not read the descriptor).
+// The segments of page p are pool[p * SEG_CHUNK ...].
 struct RlePagePlan {
   int32_t status;       // status of the header walk (PQD_OK, or the failure met at output index n_out)
   uint32_t n_out;       // values covered by the segments
@@ -36,15 +42,14 @@ struct RlePagePlan {
   uint32_t nseg;
   uint32_t w;           // bit width of the ids
   uint32_t flags;       // PLAN_F_*
-  uint32_t nchunks;
   uint32_t stream_end;  // offset from `data` where the hybrid stream ends
+  uint32_t data_len;
   uint64_t data;        // copies of the descriptor's pointers
   uint64_t out;
   uint64_t dict;
   uint32_t dict_len;
-  uint32_t data_len;
-  uint32_t chunk[MAX_PLAN_CHUNKS];  // pool chunk numbers, in order (chunk[0] == page number)
+  uint32_t reserved;
 };
-static_assert(sizeof(RlePagePlan) == 128, "plan record is 128 bytes");
+static_assert(sizeof(RlePagePlan) == 64, "plan record is 64 bytes");
 
 }  // namespace pqd
