@@ -40,8 +40,6 @@ constexpr int DS_R = DS_TILE_VALUES / DS_THREADS;  // values per lane per tile
 constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;         // one page's segments
 constexpr int DS_PLAN_BYTES = 64;
 
-constexpr int DS_NWP = 3;  // packed dwords kept per unit (enough for widths <= 16; wider: value by value)
-
 constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;               // three segment buffers
 constexpr int DS_OFF_PLANS = DS_OFF_SEGS + 3 * DS_SEG_BYTES;  // three plan records
 constexpr int DS_OFF_STATE = DS_OFF_PLANS + 4 * DS_PLAN_BYTES;
@@ -74,7 +72,6 @@ static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag b
 struct DsShared {
   uint32_t oob_at[3];  // first out-of-range id of the page in plan buffer 0 / 1 / 2
   uint32_t pad;
-  uint32_t dummy[4];  // what lanes without a lookup read (never written after the prologue)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -106,6 +103,14 @@ __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmc
 // the same 16-byte block).
 __device__ __forceinline__ void load_slice(const uint8_t* slice_src, uint32_t bytes, uint32_t lds_buf, uint32_t wave,
                                            uint32_t lane) {
+  if (bytes == DS_SLICE_BYTES) {  // no per-lane bounds to check
+#pragma unroll
+    for (int i = 0; i < (int)(DS_SLICE_BYTES / 16 / DS_THREADS); ++i) {
+      const uint32_t piece0 = ((uint32_t)i * DS_WAVES + wave) * 64;  // wave-uniform
+      dma16(slice_src + (size_t)piece0 * 16, lane * 16, lds_buf + piece0 * 16);
+    }
+    return;
+  }
   const uint32_t pieces = (bytes + 15) >> 4;
 #pragma unroll
   for (int i = 0; i < (int)(DS_SLICE_BYTES / 16 / DS_THREADS); ++i) {
@@ -129,21 +134,24 @@ __device__ __forceinline__ void fetch_plan_async(const RlePagePlan* plans, const
 // Page constants, read from the plan record in LDS and held in scalar registers.
 struct PageHead {
   const PQD_GLOBAL uint32_t* words;  // `data` rounded down to a dword
+  const PQD_GLOBAL uint32_t* load_words;  // base of the 12-byte unit loads (`words`, or a harmless address)
   uint32_t in_off;                   // data & 3
-  uint32_t last_word;                // index of the last dword that holds a byte of the page
+  uint32_t max_wi;                   // largest dword index a 12-byte unit load may start at
   uint32_t full_words;               // dwords lying wholly before the end of the stream
   uint32_t tail_mask;                // valid bytes of dword `full_words` (0: none)
   uint32_t n_out, w, nseg, flags;
+  bool no_fast;                      // no unit of this page can take the 12-byte path
 };
 
-__device__ __forceinline__ PageHead read_head(const PQD_LDS RlePagePlan* pl) {
+// `spare` is any 12 readable bytes: what the unit loads read when a page gives them nothing to read.
+__device__ __forceinline__ PageHead read_head(const PQD_LDS RlePagePlan* pl, const void* spare) {
   PageHead h;
   const uint32_t dlo = uni((uint32_t)pl->data), dhi = uni((uint32_t)(pl->data >> 32));
   const uint64_t data = ((uint64_t)dhi << 32) | dlo;
   h.in_off = dlo & 3u;
   h.words = (const PQD_GLOBAL uint32_t*)(data - h.in_off);
   const uint32_t data_len = uni(pl->data_len), stream_end = uni(pl->stream_end);
-  h.last_word = data_len ? (h.in_off + data_len - 1) >> 2 : 0u;
+  const uint32_t last_word = data_len ? (h.in_off + data_len - 1) >> 2 : 0u;  // last dword holding a byte of the page
   const uint32_t end_bytes = h.in_off + stream_end;
   h.full_words = end_bytes >> 2;
   h.tail_mask = (end_bytes & 3u) ? ((1u << (8 * (end_bytes & 3u))) - 1u) : 0u;
@@ -151,77 +159,63 @@ __device__ __forceinline__ PageHead read_head(const PQD_LDS RlePagePlan* pl) {
   h.w = uni(pl->w);
   h.nseg = uni(pl->nseg);
   h.flags = uni(pl->flags);
+  // ids of up to 16 bits: four of them, at any bit offset, lie inside three dwords
+  h.no_fast = last_word < 2 || h.w > 16 || (h.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) != 0 || h.n_out == 0;
+  h.max_wi = h.no_fast ? 0u : last_word - 2;
+  h.load_words = h.no_fast ? (const PQD_GLOBAL uint32_t*)spare : h.words;
   return h;
 }
 
 // The packed dwords a unit of four values needs, fetched but not yet consumed.
-template <int NW>
 struct UnitRaw {
-  uint32_t d[NW];
-  uint32_t meta;  // bits 0..4: bit offset inside d[0]; bits 8..9: kind; bits 16..: segment index
+  u32x3_a4 d;
+  uint32_t meta;  // bits 0..4: bit offset inside d.x; bits 8..9: kind; bits 16..: segment index
 };
 constexpr uint32_t UK_NONE = 0, UK_PACKED = 1, UK_RLE = 2, UK_SLOW = 3;
 
-__device__ __forceinline__ uint32_t seg_start(const PQD_LDS RleSeg* cs, uint32_t i) {
-  return cs[i].start_kind & SEG_START_MASK;
-}
-
-// For every unit of the page's values [0, t1): find its segment and ISSUE the global loads of its packed
-// dwords.  Nothing waits on the loads here, so all units' loads are in flight together (and, when
-// this is called for the next page during a sweep, they complete behind the sweep).  NW = dwords
-// kept per unit: units of wider ids (ceil((31 + 4w) / 32) > NW) are marked for the value-by-value
-// path, as are units that straddle segments or lie in a segment cut short by the end of the stream.
-template <int UNITS, int NW>
-__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t t1, const PageHead& h,
-                                             uint32_t tid, UnitRaw<NW> (&raw)[UNITS] PROF_FN_PARAM) {
-  constexpr uint32_t t0 = 0;
-  const uint32_t nw = (62u + 4u * h.w) >> 5;
-  // segment of every unit: a branch-free binary search, the units' steps interleaved so that
-  // each step is one LDS round trip for all of them
-  uint32_t seg[UNITS];
-#pragma unroll
-  for (int k = 0; k < UNITS; ++k) seg[k] = 0;
-#pragma unroll
-  for (uint32_t half = SEG_CHUNK / 2; half; half >>= 1) {
-#pragma unroll
-    for (int k = 0; k < UNITS; ++k) {
-      const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-      const uint32_t m = seg[k] + half;
-      const uint32_t st = seg_start(cs, m < count ? m : count - 1);
-      seg[k] = (m < count && st <= g0) ? m : seg[k];
-    }
-  }
-  PROF(10)
-  // Classification and addresses are plain arithmetic and the loads are issued by every lane for
-  // every unit (units without packed dwords read the first dwords of the page): a load whose
-  // destination register is also written on another control-flow path would have to be waited
-  // for on the spot, one memory round trip per unit.
+// For every unit (four consecutive values, unit k of lane t starts at value 4 * (k * 1024 + t)) of
+// the page's values [0, t1): find its segment, classify it and ISSUE the 12-byte load of its
+// packed dwords.  Nothing waits on the loads here (they complete behind the sweep of the page
+// before), and every lane issues every load (units with nothing to read take dwords 0..2): a load
+// whose destination is also written on another control-flow path would have to be waited for on
+// the spot.  Units that straddle segments, lie in a segment cut short by the end of the stream,
+// or hold ids wider than 16 bits are marked for the value-by-value path.
+template <int UNITS>
+__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t t1, const PageHead& h, uint32_t tid,
+                                             uint32_t wave, UnitRaw (&raw)[UNITS] PROF_FN_PARAM) {
+  const PQD_LDS uint8_t* table = (const PQD_LDS uint8_t*)(cs + SEG_TABLE_SLOT);
+  const uint32_t t1x4 = t1 << 2;
   uint32_t wi[UNITS];
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
-    const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-    const uint32_t sg = seg[k];
-    const uint32_t sk = cs[sg].start_kind, src = cs[sg].src;
-    const uint32_t s_begin = sk & SEG_START_MASK;
-    const uint32_t s_end = sg + 1 < count ? seg_start(cs, sg + 1) : h.n_out;
+    const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+    const uint32_t g4 = g0 * 4 + 3;  // start4 <= g4  <=>  start <= g0
+    // the unit row of a wave is one block of the table; from its first segment walk forward
+    uint32_t sg = uni(table[(uint32_t)k * (DS_THREADS * 4 / SEG_BLOCK) + wave]);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) sg += cs[sg + 1].start4 <= g4 ? 1u : 0u;  // valid lanes stop at the sentinel
+    for (;;) {  // rare: more than two segment boundaries inside 256 values
+      const bool adv = g0 < t1 && cs[sg + 1].start4 <= g4;
+      if (!__builtin_amdgcn_ballot_w64(adv)) break;
+      sg += adv ? 1u : 0u;
+    }
+    const uint32_t sk = cs[sg].start4, src = cs[sg].src;
+    const uint32_t e4 = cs[sg + 1].start4;
+    const uint32_t lim4 = e4 < t1x4 ? e4 : t1x4;
     const bool is_packed = (sk & SEG_PACKED_BIT) != 0;
-    const bool whole = g0 + 4 <= t1 && g0 + 4 <= s_end && !(sk & SEG_PARTIAL_BIT) && (nw <= (uint32_t)NW || !is_packed);
+    const bool whole = g0 * 4 + 16 <= lim4 && !(sk & SEG_PARTIAL_BIT);
     // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
     const uint32_t byte0 = h.in_off + src;
-    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - s_begin) * h.w;
-    const uint32_t kind = g0 >= t1 ? UK_NONE : (!whole ? UK_SLOW : (is_packed ? UK_PACKED : UK_RLE));
-    wi[k] = kind == UK_PACKED ? (byte0 >> 2) + (bitrel >> 5) : 0u;
-    raw[k].meta = (kind == UK_PACKED ? (bitrel & 31u) : 0u) | (kind << 8) | (sg << 16);
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk >> 2)) * h.w;
+    const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
+    const bool fast = whole && is_packed && !h.no_fast && w_i <= h.max_wi;
+    const uint32_t kind = g0 >= t1 ? UK_NONE : (is_packed ? (fast ? UK_PACKED : UK_SLOW) : (whole ? UK_RLE : UK_SLOW));
+    wi[k] = kind == UK_PACKED ? w_i : 0u;
+    raw[k].meta = (bitrel & 31u) | (kind << 8) | (sg << 16);
   }
   PROF(11)
 #pragma unroll
-  for (int k = 0; k < UNITS; ++k) {
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const uint32_t idx = wi[k] + j < h.last_word ? wi[k] + j : h.last_word;  // never past the page
-      raw[k].d[j] = h.words[idx];
-    }
-  }
+  for (int k = 0; k < UNITS; ++k) raw[k].d = *(const PQD_GLOBAL u32x3_a4*)(h.load_words + wi[k]);
 }
 
 __device__ __forceinline__ uint32_t guarded_word(const PageHead& h, uint32_t i) {
@@ -230,53 +224,62 @@ __device__ __forceinline__ uint32_t guarded_word(const PageHead& h, uint32_t i) 
   return 0u;  // at or past the end of the stream
 }
 
-// Turns the fetched dwords into ids (values at or beyond t1 stay 0).
-template <int UNITS, int NW>
-__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t count, uint32_t t1, const PageHead& h,
-                                        uint32_t tid, const UnitRaw<NW> (&raw)[UNITS], uint32_t (&id)[UNITS * 4]) {
-  constexpr uint32_t t0 = 0;
-  const uint32_t mask = mask32(h.w);
+// Value j of a unit whose 64 aligned bits are {hi, lo}; w <= 16 and j are wave-uniform.
+__device__ __forceinline__ uint32_t unit_value(uint32_t lo, uint32_t hi, uint32_t w, uint32_t j) {
+  const uint32_t off = j * w;
+  if (off + w <= 32) return __builtin_amdgcn_ubfe(lo, off, w);
+  if (off >= 32) return __builtin_amdgcn_ubfe(hi, off - 32, w);
+  return funnel_shr(lo, hi, off) & ((1u << w) - 1u);
+}
+
+// Turns the fetched dwords into ids (values at or beyond t1 become 0).
+template <int UNITS>
+__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t t1, const PageHead& h, uint32_t tid,
+                                        const UnitRaw (&raw)[UNITS], uint32_t (&id)[UNITS * 4]) {
+  const uint32_t w = h.w <= 16 ? h.w : 0u;  // wider ids never take the 12-byte path
   bool any_slow = false;
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
     const uint32_t kind = (raw[k].meta >> 8) & 3u;
-    Window5 wnd = {raw[k].d[0], NW > 1 ? raw[k].d[NW > 1 ? 1 : 0] : 0u, NW > 2 ? raw[k].d[NW > 2 ? 2 : 0] : 0u,
-                   NW > 3 ? raw[k].d[NW > 3 ? 3 : 0] : 0u, NW > 4 ? raw[k].d[NW > 4 ? 4 : 0] : 0u};
-    wnd.shr(raw[k].meta & 31u);
-    const uint32_t a0 = wnd.d0 & mask;
-    wnd.drop(h.w);
-    const uint32_t a1 = wnd.d0 & mask;
-    wnd.drop(h.w);
-    const uint32_t a2 = wnd.d0 & mask;
-    wnd.drop(h.w);
-    const uint32_t a3 = wnd.d0 & mask;
-    const bool packed = kind == UK_PACKED;
-    const uint32_t other = kind == UK_RLE ? cs[raw[k].meta >> 16].src : 0u;  // the repeated value of an RLE run
-    id[4 * k] = packed ? a0 : other;
-    id[4 * k + 1] = packed ? a1 : other;
-    id[4 * k + 2] = packed ? a2 : other;
-    id[4 * k + 3] = packed ? a3 : other;
-    any_slow |= kind == UK_SLOW;
+    const uint32_t b = raw[k].meta & 31u;
+    const uint32_t lo = funnel_shr(raw[k].d.x, raw[k].d.y, b), hi = funnel_shr(raw[k].d.y, raw[k].d.z, b);
+    const uint32_t a0 = unit_value(lo, hi, w, 0), a1 = unit_value(lo, hi, w, 1), a2 = unit_value(lo, hi, w, 2),
+                   a3 = unit_value(lo, hi, w, 3);
+    if (__builtin_amdgcn_ballot_w64(kind != UK_PACKED) == 0) {  // the usual case: the wave's whole row is packed
+      id[4 * k] = a0;
+      id[4 * k + 1] = a1;
+      id[4 * k + 2] = a2;
+      id[4 * k + 3] = a3;
+    } else {
+      const bool packed = kind == UK_PACKED;
+      const uint32_t other = kind == UK_RLE ? cs[raw[k].meta >> 16].src : 0u;  // the repeated value of an RLE run
+      id[4 * k] = packed ? a0 : other;
+      id[4 * k + 1] = packed ? a1 : other;
+      id[4 * k + 2] = packed ? a2 : other;
+      id[4 * k + 3] = packed ? a3 : other;
+      any_slow |= kind == UK_SLOW;
+    }
   }
-  if (any_slow) {  // rare: run boundaries that are not multiples of four, truncated final runs, wide ids
+  if (__builtin_amdgcn_ballot_w64(any_slow)) {  // rare: run boundaries off multiples of four, truncated runs, wide ids
+    const uint32_t mask = mask32(h.w);
 #pragma unroll 1
     for (int k = 0; k < UNITS; ++k) {
       uint32_t meta = 0;
 #pragma unroll
       for (int kk = 0; kk < UNITS; ++kk) meta = kk == k ? raw[kk].meta : meta;  // k is not a compile-time constant
       if (((meta >> 8) & 3u) != UK_SLOW) continue;
-      const uint32_t g0 = t0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
       uint32_t t = meta >> 16;
       uint32_t v[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t g = g0 + j;
         if (g >= t1) continue;
-        while (t + 1 < count && seg_start(cs, t + 1) <= g) ++t;
-        const uint32_t tk = cs[t].start_kind, src = cs[t].src;
+        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == n_out > g)
+        const uint32_t tk = cs[t].start4, src = cs[t].src;
         if (tk & SEG_PACKED_BIT) {
           const uint32_t byte0 = h.in_off + src;
-          const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk & SEG_START_MASK)) * h.w;
+          const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
           const uint32_t wi = (byte0 >> 2) + (bitrel >> 5);
           v[j] = funnel_shr(guarded_word(h, wi), guarded_word(h, wi + 1), bitrel & 31u) & mask;
         } else {
@@ -307,15 +310,15 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
   constexpr int R = DS_R;
   constexpr int UNITS = R / 4;
-  constexpr int NWP = DS_NWP;
   constexpr uint32_t S = DS_SLICE_BYTES / ELEM;  // dictionary entries per slice
   const uint32_t tid = threadIdx.x;
-  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  const uint32_t wave = uni(tid >> 6), lane = tid & 63u;
 
   // which slice each LDS buffer holds (uniform over the workgroup)
   uint64_t tag_dict = 0;
   uint32_t tag_s0 = ~0u, tag_s1 = ~0u;
-  uint32_t q = 0;  // pass counter: pass q uses buffer q & 1
+  uint32_t last_buf = 1;   // buffer of the latest pass
+  bool descending = false;  // slice order of the current page
 
   uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -328,30 +331,21 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     fetch_plan_async(plans, pool, page + stride, lds0 + DS_OFF_SEGS + DS_SEG_BYTES, lds0 + DS_OFF_PLANS + DS_PLAN_BYTES, wave,
                      lane);
   if (tid < 3) sh->oob_at[tid] = ~0u;
-  if (tid < 4) sh->dummy[tid] = 0;
   wg_barrier();
 
-  // a head whose loads all hit one valid dword, for when there is no page to prefetch
-  PageHead idle;
-  idle.words = (const PQD_GLOBAL uint32_t*)plans;
-  idle.in_off = idle.last_word = idle.full_words = idle.tail_mask = 0;
-  idle.n_out = idle.w = idle.flags = 0;
-  idle.nseg = 1;
-
-  UnitRaw<NWP> raw[UNITS];  // packed dwords of the page about to be decoded
+  UnitRaw raw[UNITS];  // packed dwords of the page about to be decoded
   PROF_INIT
   {
-    const PageHead h0 = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS));
-    const bool ok = !(h0.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) && h0.n_out > 0;
-    const PageHead& f = ok ? h0 : idle;
-    locate_fetch<UNITS, NWP>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), f.nseg, f.n_out, f, tid, raw PROF_FN_ARG);
+    const PageHead h0 = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS), plans);
+    const bool ok = !(h0.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
+    locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), ok ? h0.n_out : 0u, h0, tid, wave, raw PROF_FN_ARG);
   }
 
   for (;;) {
     const uint32_t nb = pb == 2 ? 0u : pb + 1, nnb = nb == 2 ? 0u : nb + 1;
     const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + pb * DS_SEG_BYTES);
     const PQD_LDS RlePagePlan* lpl = (const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + pb * DS_PLAN_BYTES);
-    const PageHead h = read_head(lpl);
+    const PageHead h = read_head(lpl, plans);
     const bool skip = (h.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) != 0;
     const uint32_t n_out = skip ? 0u : h.n_out;  // at most DS_TILE_VALUES (the plan kernel sees to it)
     const uint32_t dict_len = uni(lpl->dict_len);
@@ -371,56 +365,61 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
     // ---- 1. ids into registers (their packed dwords were requested one page ago)
     uint32_t id[R];
-    extract<UNITS, NWP>(cs, skip ? 1u : h.nseg, n_out, h, tid, raw, id);
+    extract<UNITS>(cs, n_out, h, tid, raw, id);
     PROF(1)
 
     // ---- 2. prefetch: the plan of the page after the next, the packed dwords of the next page.
     // The loads are issued unconditionally (from a harmless address when there is nothing to
-    // fetch) so that exactly NWP * UNITS of them are this wave's most recent memory operations
-    // when it reaches the first barrier of the sweep.
+    // fetch) so that exactly UNITS of them are this wave's most recent memory operations when it
+    // reaches the first barrier of the sweep.
     if (next_page + stride < n_pages && next_page + stride >= next_page)
       fetch_plan_async(plans, pool, next_page + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES,
                        lds0 + DS_OFF_PLANS + nnb * DS_PLAN_BYTES, wave, lane);
     {
-      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES));
-      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) && nh.n_out > 0;
-      const PageHead& f = ok ? nh : idle;
-      locate_fetch<UNITS, NWP>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), f.nseg, f.n_out, f, tid, raw PROF_FN_ARG);
+      // without a next page this reads the stale record of an earlier page (or nothing fetched
+      // yet): only its load base is used, and read_head makes that harmless for unusable records
+      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES), plans);
+      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
+      locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), ok ? nh.n_out : 0u, nh, tid, wave,
+                          raw PROF_FN_ARG);
     }
     PROF(8)
 
-    // ---- 3. ids beyond the dictionary: flag the first one, never look them up.
-    // `done` has one bit per register slot: set = nothing (more) to look up for it.
-    uint32_t done = 0;
-    {
+    // ---- 3. ids beyond the dictionary: note the first one, and look up entry 0 instead.
+    // A page whose id width cannot express such an id skips the check.
+    if (h.w >= 32 || (1u << h.w) > dict_len) {
       uint32_t bad = ~0u;
 #pragma unroll
       for (int k = UNITS - 1; k >= 0; --k) {
         const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
-          const bool live = g0 + j < n_out;
           const bool over = id[4 * k + j] >= dict_len;
-          bad = (live && over) ? g0 + j : bad;
-          done |= (!live || over) ? (1u << (4 * k + j)) : 0u;
-          id[4 * k + j] = (!live || over) ? 0u : id[4 * k + j];
+          bad = (over && g0 + j < n_out) ? g0 + j : bad;
+          id[4 * k + j] = over ? 0u : id[4 * k + j];
         }
       }
       if (bad != ~0u) atomicMin(&sh->oob_at[pb], bad);
     }
     PROF(2)
 
-    // ---- 4. gather.  id[r] is replaced IN PLACE by the low word of its value once its slice has
-    // come by (vhi[r] receives the high word of 8-byte values).
-    uint32_t vhi[ELEM == 8 ? R : 1];
-    if (ELEM == 8) {
+    // ---- 4. gather: every pass looks up the ids that fall into the resident slice.
+    // Byte offsets into the dictionary, so that a pass costs a subtraction and a compare per id.
 #pragma unroll
-      for (int r = 0; r < R; ++r) vhi[ELEM == 8 ? r : 0] = 0;
+    for (int r = 0; r < R; ++r) id[r] *= ELEM;
+    uint32_t vlo[R], vhi[ELEM == 8 ? R : 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      vlo[r] = 0;
+      vhi[ELEM == 8 ? r : 0] = 0;
     }
+    // Pass order alternates between pages (0,1,..,P-1 then P-1,..,1,0): the two slices a page ends
+    // with are the two the next page starts with, so a page moves only P - 2 slices into LDS.
     bool prefetch_only = true;  // this wave's memory operations since the last barrier: the prefetch loads alone
-    for (uint32_t s = 0; s < P; ++s, ++q) {
-      const uint32_t curb = q & 1u;
-      // the slice this pass needs, if no earlier pass prefetched it
+    for (uint32_t i = 0; i < P; ++i) {
+      const uint32_t s = descending ? P - 1 - i : i;
+      uint32_t curb = tag_s0 == s ? 0u : (tag_s1 == s ? 1u : last_buf ^ 1u);
+      // the slice this pass needs, if it is not resident
       if ((curb ? tag_s1 : tag_s0) != s) {
         wg_barrier();  // nobody still reads this buffer
         const uint32_t n_here = dict_len - s * S < S ? dict_len - s * S : S;
@@ -431,18 +430,19 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
           tag_s0 = s;
         prefetch_only = false;
       }
+      last_buf = curb;
       PROF(5)
       // this pass's slice has landed; everybody is done with the other buffer
       if (prefetch_only)
-        wg_barrier_keep<NWP * UNITS>();  // the prefetch loads stay in flight
+        wg_barrier_keep<UNITS>();  // the prefetch loads stay in flight
       else
         wg_barrier();
       prefetch_only = false;
       PROF(3)
-      // prefetch the slice of the next pass (the next page usually uses the same dictionary)
-      {
-        const uint32_t nx = s + 1 < P ? s + 1 : 0u;
-        if ((curb ? tag_s0 : tag_s1) != nx) {
+      // bring in the slice of the next pass
+      if (i + 1 < P) {
+        const uint32_t nx = descending ? s - 1 : s + 1;
+        if (tag_s0 != nx && tag_s1 != nx) {
           const uint32_t n_here = dict_len - nx * S < S ? dict_len - nx * S : S;
           load_slice(dict_bytes + (size_t)nx * DS_SLICE_BYTES, n_here * ELEM, lds0 + (curb ^ 1u) * DS_SLICE_BYTES, wave, lane);
           if (curb)
@@ -452,30 +452,19 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
         }
       }
       PROF(9)
-      const uint32_t s0 = s * S;
-      if (ELEM == 4) {
-        const PQD_LDS uint32_t* buf = (const PQD_LDS uint32_t*)(lds + curb * DS_SLICE_BYTES);
+      const uint32_t s0b = s * DS_SLICE_BYTES;
+      const PQD_LDS uint8_t* buf = (const PQD_LDS uint8_t*)(lds + curb * DS_SLICE_BYTES);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint32_t idx = id[r] - s0;
-          if (idx < S && !(done & (1u << r))) {
-            id[r] = buf[idx];
-            done |= 1u << r;
+      for (int r = 0; r < R; ++r) {
+        const uint32_t a = id[r] - s0b;
+        if (a < DS_SLICE_BYTES) {
+          if (ELEM == 4) {
+            vlo[r] = *(const PQD_LDS uint32_t*)(buf + a);
+          } else {
+            const u32x2 t = *(const PQD_LDS u32x2*)(buf + a);
+            vlo[r] = t.x;
+            vhi[ELEM == 8 ? r : 0] = t.y;
           }
-        }
-      } else {
-        const PQD_LDS u32x2* buf = (const PQD_LDS u32x2*)(lds + curb * DS_SLICE_BYTES);
-        const PQD_LDS u32x2* dummy = (const PQD_LDS u32x2*)(sh->dummy);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint32_t idx = id[r] - s0;
-          const bool hit = idx < S && !(done & (1u << r));
-          const PQD_LDS u32x2* p = hit ? buf + idx : dummy;  // lanes with nothing to fetch read one shared word
-          const u32x2 t = *p;
-          id[r] = hit ? t.x : id[r];
-          vhi[ELEM == 8 ? r : 0] = hit ? t.y : vhi[ELEM == 8 ? r : 0];
-          done |= hit ? (1u << r) : 0u;
-          if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // bounds the lookups in flight, and so the registers
         }
       }
       PROF(4)
@@ -489,30 +478,31 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
       if (ELEM == 4) {
         PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
         if (g0 + 4 <= n_out) {
-          u32x4_a4 r4 = {id[4 * k], id[4 * k + 1], id[4 * k + 2], id[4 * k + 3]};
+          u32x4_a4 r4 = {vlo[4 * k], vlo[4 * k + 1], vlo[4 * k + 2], vlo[4 * k + 3]};
           *(PQD_GLOBAL u32x4_a4*)(o) = r4;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (g0 + j < n_out) o[j] = id[4 * k + j];
+            if (g0 + j < n_out) o[j] = vlo[4 * k + j];
         }
       } else {
         PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)out_addr + g0;
         if (g0 + 4 <= n_out) {
-          u32x4_a4 r0 = {id[4 * k], vhi[ELEM == 8 ? 4 * k : 0], id[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
-          u32x4_a4 r1 = {id[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], id[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
+          u32x4_a4 r0 = {vlo[4 * k], vhi[ELEM == 8 ? 4 * k : 0], vlo[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
+          u32x4_a4 r1 = {vlo[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], vlo[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
           *(PQD_GLOBAL u32x4_a4*)(o) = r0;
           *(PQD_GLOBAL u32x4_a4*)(o + 2) = r1;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (g0 + j < n_out) {
-              u32x2_a4 x = {id[4 * k + j], vhi[ELEM == 8 ? 4 * k + j : 0]};
+              u32x2_a4 x = {vlo[4 * k + j], vhi[ELEM == 8 ? 4 * k + j : 0]};
               o[j] = x;
             }
         }
       }
     }
+    if (P > 1) descending = !descending;
     PROF(6)
 
     // ---- 6. page end.  All atomicMin on this page's oob slot are in after the barrier; the slot is

@@ -46,7 +46,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
   uint32_t blk = 0, blk_pos = pos0, next_stride = st.next_stride;  // block that may hold the next header
   int32_t status = PQD_OK;
   bool need_round = false;
-  while (ns < SEG_CHUNK && vals < n_values) {
+  while (ns < (uint32_t)SEG_MAX + 1 && vals < n_values) {
     const uint32_t rem = n_values - vals;
     if (pending == 0) {
       if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
@@ -111,7 +111,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
         next_stride = pos - run_pos;
         // a zero-count run leaves currentCount negative: its value repeats for the rest of the page
         const uint32_t take = (count == 0 || count > rem) ? rem : count;
-        stage[ns].start_kind = vals;
+        stage[ns].start4 = vals << 2;
         stage[ns].src = value;
         ++ns;
         vals += take;
@@ -145,7 +145,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
     if (zeros) {
       g = pending < want ? pending : want;
       const uint32_t take = g * 8 > rem ? rem : g * 8;
-      stage[ns].start_kind = vals;
+      stage[ns].start4 = vals << 2;
       stage[ns].src = 0;
       ++ns;
       vals += take;
@@ -154,7 +154,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
     }
     const uint32_t bytes = g * w;
     const uint32_t take = g * 8 > rem ? rem : g * 8;
-    stage[ns].start_kind = vals | SEG_PACKED_BIT | (bytes > avail ? SEG_PARTIAL_BIT : 0u);
+    stage[ns].start4 = (vals << 2) | SEG_PACKED_BIT | (bytes > avail ? SEG_PARTIAL_BIT : 0u);
     stage[ns].src = pos;
     ++ns;
     vals += take;
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     return;
   }
 
-  // segment start indices hold 30 bits, and the sliced dictionary kernel holds a whole page in
-  // its registers: leave larger pages to the generic kernel
-  if (n_values > SEG_START_MASK || (want_dict && n_values > DS_TILE_VALUES)) {
+  // segment start indices hold 30 bits; the sliced dictionary kernel holds a whole page in its
+  // registers and reads ids of up to 16 bits: leave other pages to the generic kernel
+  if (n_values > SEG_START_MAX || (want_dict && (n_values > DS_TILE_VALUES || w > 16))) {
     if (tid == 0) {
       RlePagePlan pl = {};
       pl.flags = PLAN_F_FALLBACK;
@@ -306,15 +306,38 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     __syncthreads();
     const uint32_t ns = st.nstage;
     const bool done = st.done != 0;
-    if (ns == SEG_CHUNK && !done) {  // more segments than a planned page may have
+    if (ns > (uint32_t)SEG_MAX) {  // more segments than a planned page may have
       fallback = true;
       break;
     }
     if (done) {
-      // the segments of page p are pool chunk p
+      const uint32_t n_out = st.vals;
+      if (tid == 0) stage[ns].start4 = n_out << 2;  // sentinel
+      __syncthreads();
+      // block table: the segment holding value SEG_BLOCK * b (lower-bound search, one block per lane and turn)
+      uint8_t* table = reinterpret_cast<uint8_t*>(stage + SEG_TABLE_SLOT);
+      for (uint32_t b = tid; b < (uint32_t)SEG_TABLE_BLOCKS; b += PLAN_THREADS) {
+        const uint32_t first = b * SEG_BLOCK;
+        uint32_t lo = 0, hi = ns;  // start[lo] <= first < start[hi]
+        if (first >= n_out) {
+          lo = ns ? ns - 1 : 0;
+        } else {
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((stage[mid].start4 >> 2) <= first)
+              lo = mid;
+            else
+              hi = mid;
+          }
+        }
+        table[b] = (uint8_t)lo;
+      }
+      __syncthreads();
+      // the chunk of page p is pool chunk p: segments + sentinel, and the table
       const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
       uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (size_t)page * SEG_CHUNK);
-      for (uint32_t i = tid; i < ns * 2; i += PLAN_THREADS) dst[i] = src[i];
+      for (uint32_t i = tid; i < (ns + 1) * 2; i += PLAN_THREADS) dst[i] = src[i];
+      for (uint32_t i = SEG_TABLE_SLOT * 2 + tid; i < (uint32_t)SEG_CHUNK * 2; i += PLAN_THREADS) dst[i] = src[i];
       nseg = ns;
       break;
     }

@@ -103,12 +103,12 @@ int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
   return PQD_OK;
 }
 
-// Which kernels decode dictionary pages.  PQD_DICT_PATH=sliced selects the planned path (header-walk
-// kernel + LDS-sliced gather); anything else, or nothing, the single generic kernel.  Read on every
-// call so that a test can switch between the two inside one process.
+// Which kernels decode dictionary pages: the planned path (header-walk kernel + LDS-sliced gather,
+// with the generic kernel for the pages the plan leaves to it) unless PQD_DICT_PATH=generic asks
+// for the single generic kernel.  Read on every call so that a test can switch inside one process.
 bool use_sliced_dictionary_path() {
   const char* v = getenv("PQD_DICT_PATH");
-  return v && strcmp(v, "sliced") == 0;
+  return !(v && strcmp(v, "generic") == 0);
 }
 
 int class_of(const pqd_page_desc& d) {  // pages that can share a launch

@@ -10,6 +10,7 @@ namespace pqd {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 

@@ -13,15 +13,25 @@ namespace pqd {
 
 // One segment = a run, or a piece of a bit-packed run, whose values are consecutive in the output.
 struct RleSeg {
-  uint32_t start_kind;  // bits 0..29: output index of the first value; bit 31: bit-packed;
-                        // bit 30: bit-packed and cut short by the end of the stream (missing bytes are zero)
-  uint32_t src;         // bit-packed: stream offset of the first group; RLE: the repeated value
+  uint32_t start4;  // (output index of the first value << 2) | SEG_PACKED_BIT | SEG_PARTIAL_BIT.
+                    // With the flags below the index, start4 values compare like the indices.
+  uint32_t src;     // bit-packed: stream offset of the first group; RLE: the repeated value
 };
 
-constexpr uint32_t SEG_PACKED_BIT = 0x80000000u;
-constexpr uint32_t SEG_PARTIAL_BIT = 0x40000000u;
-constexpr uint32_t SEG_START_MASK = 0x3FFFFFFFu;
-constexpr int SEG_CHUNK = 256;            // segments a planned page may have (2 KiB of pool per page); beyond: generic kernel
+constexpr uint32_t SEG_PACKED_BIT = 1u;   // bit-packed
+constexpr uint32_t SEG_PARTIAL_BIT = 2u;  // bit-packed and cut short by the end of the stream (missing bytes are zero)
+constexpr uint32_t SEG_START_MAX = 0x3FFFFFFFu;
+
+// The pool holds one chunk of SEG_CHUNK 8-byte slots per page:
+//   slots 0 .. nseg-1          the segments
+//   slot  nseg                 a sentinel whose start is n_out (so "start of the next segment" always exists)
+//   slots SEG_TABLE_SLOT ..    one byte per block of SEG_BLOCK output values: the segment that holds
+//                              the block's first value (a wave's unit row is one such block)
+constexpr int SEG_CHUNK = 256;
+constexpr int SEG_TABLE_SLOT = 240;
+constexpr int SEG_MAX = SEG_TABLE_SLOT - 1;  // segments a planned page may have; beyond: generic kernel
+constexpr int SEG_BLOCK = 256;
+constexpr int SEG_TABLE_BLOCKS = (SEG_CHUNK - SEG_TABLE_SLOT) * 8;  // 128 blocks = 32768 values
 constexpr int PLAN_SEG_MAX_BYTES = 6144;  // payload bytes of one bit-packed segment
 
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
@@ -31,10 +41,11 @@ constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too ma
 // sweep.  The plan kernel uses them to decide whether sweeping the dictionary pays for a page.
 constexpr uint32_t DS_SLICE_BYTES = 64 * 1024;
 constexpr uint32_t DS_TILE_VALUES = 1024 * 20;
+static_assert(DS_TILE_VALUES <= SEG_TABLE_BLOCKS * SEG_BLOCK, "the block table covers a whole tile");
 constexpr uint32_t DS_MAX_PASSES = 32;
 
 // Everything the expansion kernel needs to know about a page (it does not read the descriptor).
-// The segments of page p are pool[p * SEG_CHUNK ...].
+// The segment chunk of page p is pool[p * SEG_CHUNK ...].
 struct RlePagePlan {
   int32_t status;       // status of the header walk (PQD_OK, or the failure met at output index n_out)
   uint32_t n_out;       // values covered by the segments
