@@ -216,6 +216,47 @@ def test_dictionary_pages(gpu, orc, dtype, dict_path):
         assert (guard == 0xA5).all()
 
 
+@pytest.mark.parametrize("elem", [4, 8])
+def test_dictionary_pages_many_mixed(gpu, orc, elem, dict_path):
+    """Hundreds of pages in one launch (each workgroup of the planned path walks several), with run
+    boundaries off multiples of four, several dictionaries, truncated streams, ids beyond the
+    dictionary, and pages the planned path hands to the generic kernel (too long, too many runs)."""
+    import parquet_java_amd as pq
+    rng = np.random.default_rng(1234 + elem)
+    ut = np.uint32 if elem == 4 else np.uint64
+    dicts = []
+    for dn in (1, 3, 17, 300, 5000, 16384, 16385, 40000, 65536):
+        raw = rng.integers(0, 1 << 63, dn, dtype=np.uint64)
+        dicts.append(raw.astype(np.uint32) if elem == 4 else raw)
+    pages, expect = [], []
+    for i in range(700):
+        dic = dicts[int(rng.integers(0, len(dicts)))]
+        dn = dic.size
+        n = int(rng.choice([1, 7, 8, 9, 63, 500, 4096, 19999, 20000, 20480, 20481, 30000])) if i % 3 else int(rng.integers(1, 20481))
+        ids = np.empty(n, np.int32)
+        pos = 0
+        mean_run = int(rng.choice([2, 11, 60, 700, 5000]))
+        while pos < n:
+            ln = min(n - pos, 1 + int(rng.geometric(1.0 / mean_run)))
+            if rng.random() < 0.5:
+                ids[pos:pos + ln] = rng.integers(0, dn)
+            else:
+                ids[pos:pos + ln] = rng.integers(0, dn, ln)
+            pos += ln
+        if i % 41 == 0:
+            ids[int(rng.integers(0, n))] = dn + int(rng.integers(0, 5))  # beyond the dictionary
+        page = orc.dict_encode_ids(ids, max(dn, int(ids.max()) + 1))
+        if i % 29 == 0 and len(page) > 3:
+            page = page[:len(page) - int(rng.integers(1, min(len(page) - 1, 40)))]  # stream cut short
+        pages.append(gpu.Page(page, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        expect.append(orc.dict_decode(page, dic, n))
+    res = gpu.decode_pages(pages)
+    for i, ((st, written, consumed, out, guard), (ost, ovals)) in enumerate(zip(res, expect)):
+        assert st == ost and written == ovals.size, (i, st, ost, written, ovals.size, pages[i].num_values)
+        assert (out.view(ut)[:written] == ovals.view(ut)).all(), i
+        assert (guard == 0xA5).all(), i
+
+
 # ------------------------------------------------------------------------------- delta
 @pytest.mark.parametrize("elem", [4, 8])
 def test_delta_pages(gpu, orc, elem):
