@@ -114,6 +114,17 @@ int pqd_event_destroy(void* ev);
 int pqd_event_record(void* ev, void* stream);
 int pqd_event_sync(void* ev);
 int pqd_event_elapsed_ms(void* start, void* stop, float* ms);
+/*
+ * Per-kernel timing of pqd_decode_pages_dev for dictionary pages, which is a sequence of up to
+ * three launches (run-plan kernel, sliced gather kernel, generic kernel for the pages left over).
+ * While enabled, the calling thread's calls (at most 4096 of them) record HIP events between the
+ * launches on the call's stream.  pqd_phase_ms_mean waits for those calls, returns the mean
+ * duration of each of the three launches in milliseconds and the number of calls averaged, and
+ * starts a new series (disabling only pauses the recording).  No counterpart in the reference;
+ * off by default.
+ */
+int pqd_set_phase_timing(int enable);
+int pqd_phase_ms_mean(float ms[3], int* n_calls);
 
 /* ---- bulk bit-unpack: one bit-packed run --------------------------------------------------- */
 /*

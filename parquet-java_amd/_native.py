@@ -53,6 +53,8 @@ EXPORTS = {
     "pqd_event_destroy": ([C.c_void_p], C.c_int),
     "pqd_event_record": ([C.c_void_p, C.c_void_p], C.c_int),
     "pqd_event_sync": ([C.c_void_p], C.c_int),
+    "pqd_set_phase_timing": ([C.c_int], C.c_int),
+    "pqd_phase_ms_mean": ([C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "pqd_event_elapsed_ms": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_float)], C.c_int),
     "pqd_unpack_i32": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
     "pqd_unpack_i32_dev": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),

@@ -103,6 +103,40 @@ int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
   return PQD_OK;
 }
 
+// Optional per-launch timing of the dictionary path (pqd_set_phase_timing): one set of four
+// events per timed call, kept until pqd_phase_ms_mean reads them.
+struct PhaseTimer {
+  bool enabled = false;
+  int device = -1;
+  std::vector<hipEvent_t> events;  // 4 per call; the first `used` sets are recorded
+  size_t used = 0;
+};
+thread_local PhaseTimer g_phase;
+constexpr size_t PHASE_MAX_CALLS = 4096;
+
+int phase_mark(int i, hipStream_t s) {
+  PhaseTimer& t = g_phase;
+  if (!t.enabled || t.used >= PHASE_MAX_CALLS) return PQD_OK;
+  if (i == 0) {
+    int dev = 0;
+    PQD_HIP(hipGetDevice(&dev));
+    if (t.device != dev) {
+      for (auto e : t.events) (void)hipEventDestroy(e);
+      t.events.clear();
+      t.used = 0;
+      t.device = dev;
+    }
+    while (t.events.size() < (t.used + 1) * 4) {
+      hipEvent_t e;
+      PQD_HIP(hipEventCreate(&e));
+      t.events.push_back(e);
+    }
+  }
+  PQD_HIP(hipEventRecord(t.events[t.used * 4 + i], s));
+  if (i == 3) ++t.used;
+  return PQD_OK;
+}
+
 // Which kernels decode dictionary pages: the planned path (header-walk kernel + LDS-sliced gather,
 // with the generic kernel for the pages the plan leaves to it) unless PQD_DICT_PATH=generic asks
 // for the single generic kernel.  Read on every call so that a test can switch inside one process.
@@ -223,6 +257,31 @@ int pqd_event_sync(void* ev) {
   PQD_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev)));
   return PQD_OK;
 }
+int pqd_set_phase_timing(int enable) {
+  g_phase.enabled = enable != 0;  // pausing keeps what has been recorded
+  return PQD_OK;
+}
+
+int pqd_phase_ms_mean(float ms[3], int* n_calls) {
+  if (!ms) return fail(PQD_BAD_ARG, "null output");
+  ms[0] = ms[1] = ms[2] = 0.f;
+  PhaseTimer& t = g_phase;
+  if (n_calls) *n_calls = (int)t.used;
+  if (t.used == 0) return PQD_OK;
+  double sum[3] = {0, 0, 0};
+  for (size_t c = 0; c < t.used; ++c) {
+    PQD_HIP(hipEventSynchronize(t.events[c * 4 + 3]));
+    for (int i = 0; i < 3; ++i) {
+      float x = 0.f;
+      PQD_HIP(hipEventElapsedTime(&x, t.events[c * 4 + i], t.events[c * 4 + i + 1]));
+      sum[i] += x;
+    }
+  }
+  for (int i = 0; i < 3; ++i) ms[i] = (float)(sum[i] / (double)t.used);
+  t.used = 0;
+  return PQD_OK;
+}
+
 int pqd_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!ms) return fail(PQD_BAD_ARG, "pqd_event_elapsed_ms: null out pointer");
   PQD_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
@@ -320,9 +379,13 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         PlanScratch ps;
         int st = plan_scratch_for(s, n_pages, &ps);
         if (st) return st;
+        if ((st = phase_mark(0, s))) return st;
         PQD_HIP(pqd::launch_rle_plan(descs, results, ps.plans, ps.pool, n_pages, true, elem_size, s));
+        if ((st = phase_mark(1, s))) return st;
         PQD_HIP(pqd::launch_dict_pages_sliced(descs, results, ps.plans, ps.pool, n_pages, elem_size, s));
+        if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, s));
+        if ((st = phase_mark(3, s))) return st;
       }
       return PQD_OK;
     case PQD_ENC_DELTA_BINARY_PACKED:
