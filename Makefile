@@ -8,7 +8,7 @@ SRCS := $(CSRC)/pqd_api.hip $(CSRC)/k_unpack.hip $(CSRC)/k_rle.hip $(CSRC)/k_rle
 HDRS := include/pqd.h $(CSRC)/pqd_device.hpp $(CSRC)/pqd_kernels.hpp $(CSRC)/pqd_rle_plan.hpp
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+all: $(LIB) oracle cpptest
 
 $(LIB): $(SRCS) $(HDRS)
 	@mkdir -p $(PKG)/lib
@@ -16,6 +16,13 @@ $(LIB): $(SRCS) $(HDRS)
 
 oracle:
 	$(MAKE) -s -C oracle libpqd_oracle.so
+
+# test program of the C++ reader mirror (include/pqd_readers.hpp); runs on the GPU box
+CPPTEST := tests/cpp/test_readers
+cpptest: $(CPPTEST)
+$(CPPTEST): tests/cpp/test_readers.cpp include/pqd_readers.hpp include/pqd.h $(LIB)
+	g++ -O1 -std=c++17 -Wall -Iinclude -o $@ $< -L$(PKG)/lib -lpqdecode_hip -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' \
+	    -Wl,-rpath-link,/opt/rocm/lib -Wl,--allow-shlib-undefined
 
 asm: $(SRCS) $(HDRS)
 	@mkdir -p build/asm
@@ -28,7 +35,7 @@ prof: $(SRCS) $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -DPQD_PROF -shared -o build/prof/libpqdecode_hip.so $(SRCS)
 
 clean:
-	rm -rf $(PKG)/lib build
+	rm -rf $(PKG)/lib build $(CPPTEST)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle asm prof clean
+.PHONY: all oracle asm prof clean cpptest
