@@ -1,0 +1,238 @@
+// Expansion of planned RLE / bit-packing hybrid pages into int32 values.
+//
+// Does the work of RunLengthBitPackingHybridDecoder.readInt (parquet-column/.../values/rle/
+// RunLengthBitPackingHybridDecoder.java:61-78) for every value of every page, but from the run plan
+// that k_rle_plan_chunks left in device memory (pqd_rle_plan.hpp), so nothing here is serial: a
+// chunk of the plan describes up to 32768 consecutive output values of one page by at most 231
+// run segments.  Workgroups take chunks from a shared counter until none are left; a lane owns
+// units of four consecutive values: it finds the unit's segment (block table + a short walk),
+// loads the unit's packed dwords with one or two loads, extracts the four values with funnel
+// shifts / bit-field extracts and stores them with one 16-byte store.
+// HBM traffic per value: w/8 bytes in, 4 bytes out; the plan adds 2 KiB per chunk.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+#include "pqd_rle_plan.hpp"
+
+namespace pqd {
+
+constexpr int EX_THREADS = 256;
+constexpr int EX_UNITS = 4;                                  // units per lane per tile
+constexpr uint32_t EX_TILE = EX_THREADS * EX_UNITS * 4;      // 4096 values
+static_assert(EX_THREADS * 4 % SEG_BLOCK == 0 && SEG_BLOCK == 256, "a wave's unit row is one table block");
+
+#define PQD_GLOBAL __attribute__((address_space(1)))
+#define PQD_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+struct ExHead {
+  const PQD_GLOBAL uint32_t* words;  // `data` rounded down to a dword
+  uint32_t in_off;                   // data & 3
+  uint32_t last_word;                // last dword holding a byte of the page
+  uint32_t full_words;               // dwords lying wholly before the end of the stream
+  uint32_t tail_mask;                // valid bytes of dword `full_words` (0: none)
+  uint32_t w;
+};
+
+__device__ __forceinline__ uint32_t ex_guarded_word(const ExHead& h, uint32_t i) {
+  if (i < h.full_words) return h.words[i];
+  if (i == h.full_words && h.tail_mask) return h.words[i] & h.tail_mask;
+  return 0u;  // at or past the end of the stream
+}
+
+// Value j of a unit whose 64 aligned bits are {hi, lo}; w <= 16 and j are wave-uniform.
+__device__ __forceinline__ uint32_t ex_unit_value(uint32_t lo, uint32_t hi, uint32_t w, uint32_t j) {
+  const uint32_t off = j * w;
+  if (off + w <= 32) return __builtin_amdgcn_ubfe(lo, off, w);
+  if (off >= 32) return __builtin_amdgcn_ubfe(hi, off - 32, w);
+  return funnel_shr(lo, hi, off) & ((1u << w) - 1u);
+}
+
+constexpr uint32_t EK_NONE = 0, EK_PACKED = 1, EK_RLE = 2, EK_SLOW = 3;
+
+// One tile of EX_TILE values starting at output index t0 (a multiple of SEG_BLOCK past v0).
+// WIDE: ids of 17..32 bits (five dwords per unit) instead of up to 16 bits (three).
+template <bool WIDE>
+__device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHead& h, uint32_t v0, uint32_t t0,
+                                            uint32_t v1, PQD_GLOBAL uint32_t* out, uint32_t tid, uint32_t wave) {
+  constexpr int NW = WIDE ? 5 : 3;
+  const PQD_LDS uint8_t* table = (const PQD_LDS uint8_t*)(cs + SEG_TABLE_SLOT);
+  const uint32_t v1x4 = v1 << 2;
+  const bool can_load = h.last_word + 1 >= (uint32_t)NW;  // the page holds at least one whole unit load
+  const uint32_t max_wi = can_load ? h.last_word + 1 - NW : 0u;
+  uint32_t wi[EX_UNITS], meta[EX_UNITS], other[EX_UNITS];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    const uint32_t g4 = g0 * 4 + 3;  // start4 <= g4  <=>  start <= g0
+    uint32_t sg = uni(table[((t0 - v0) >> 8) + (uint32_t)k * (EX_THREADS * 4 / SEG_BLOCK) + wave]);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) sg += cs[sg + 1].start4 <= g4 ? 1u : 0u;  // valid lanes stop at the sentinel
+    for (;;) {  // rare: more than two segment boundaries inside 256 values
+      const bool adv = g0 < v1 && cs[sg + 1].start4 <= g4;
+      if (!__builtin_amdgcn_ballot_w64(adv)) break;
+      sg += adv ? 1u : 0u;
+    }
+    const uint32_t sk = cs[sg].start4, src = cs[sg].src;
+    const uint32_t e4 = cs[sg + 1].start4;
+    const uint32_t lim4 = e4 < v1x4 ? e4 : v1x4;
+    const bool is_packed = (sk & SEG_PACKED_BIT) != 0;
+    const bool whole = g0 * 4 + 16 <= lim4 && !(sk & SEG_PARTIAL_BIT);
+    // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
+    const uint32_t byte0 = h.in_off + src;
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk >> 2)) * h.w;
+    const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
+    const bool fast = whole && is_packed && can_load && w_i <= max_wi;
+    const uint32_t kind = g0 >= v1 ? EK_NONE : (is_packed ? (fast ? EK_PACKED : EK_SLOW) : (whole ? EK_RLE : EK_SLOW));
+    wi[k] = kind == EK_PACKED ? w_i : 0u;
+    meta[k] = (bitrel & 31u) | (kind << 8) | (sg << 16);
+    other[k] = src;  // the repeated value of an RLE run
+  }
+  // every lane issues every load (units with nothing to read take the page's first dwords, or
+  // nothing at all when the page is shorter than one unit load)
+  uint32_t d[EX_UNITS][NW];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    if (can_load) {  // uniform
+      if (WIDE) {
+        const u32x4_a4 a = *(const PQD_GLOBAL u32x4_a4*)(h.words + wi[k]);
+        d[k][0] = a.x;
+        d[k][1] = a.y;
+        d[k][2] = a.z;
+        d[k][WIDE ? 3 : 0] = a.w;
+        d[k][WIDE ? 4 : 0] = h.words[wi[k] + 4];
+      } else {
+        const u32x3_a4 a = *(const PQD_GLOBAL u32x3_a4*)(h.words + wi[k]);
+        d[k][0] = a.x;
+        d[k][1] = a.y;
+        d[k][2] = a.z;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) d[k][j] = 0;
+    }
+  }
+  const uint32_t mask = mask32(h.w);
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    const uint32_t kind = (meta[k] >> 8) & 3u;
+    const uint32_t b = meta[k] & 31u;
+    uint32_t a0, a1, a2, a3;
+    if (WIDE) {
+      Window5 wnd = {d[k][0], d[k][1], d[k][2], d[k][WIDE ? 3 : 0], d[k][WIDE ? 4 : 0]};
+      wnd.shr(b);
+      a0 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a1 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a2 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a3 = wnd.d0 & mask;
+    } else {
+      const uint32_t lo = funnel_shr(d[k][0], d[k][1], b), hi = funnel_shr(d[k][1], d[k][2], b);
+      a0 = ex_unit_value(lo, hi, h.w, 0);
+      a1 = ex_unit_value(lo, hi, h.w, 1);
+      a2 = ex_unit_value(lo, hi, h.w, 2);
+      a3 = ex_unit_value(lo, hi, h.w, 3);
+    }
+    if (kind != EK_PACKED) a0 = a1 = a2 = a3 = other[k];
+    if (kind == EK_SLOW) {  // run boundaries off multiples of four, truncated runs, the page's last dwords
+      uint32_t t = meta[k] >> 16;
+      uint32_t v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t g = g0 + j;
+        if (g >= v1) continue;
+        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
+        const uint32_t tk = cs[t].start4, src = cs[t].src;
+        if (tk & SEG_PACKED_BIT) {
+          const uint32_t byte0 = h.in_off + src;
+          const uint64_t bitrel = (uint64_t)(byte0 & 3u) * 8 + (uint64_t)(g - (tk >> 2)) * h.w;
+          const uint32_t wj = (byte0 >> 2) + (uint32_t)(bitrel >> 5);
+          const uint32_t sh = (uint32_t)bitrel & 31u;
+          const uint32_t x0 = ex_guarded_word(h, wj), x1 = ex_guarded_word(h, wj + 1);
+          v[j] = funnel_shr(x0, x1, sh) & mask;
+        } else {
+          v[j] = src;
+        }
+      }
+      a0 = v[0];
+      a1 = v[1];
+      a2 = v[2];
+      a3 = v[3];
+    }
+    if (g0 + 4 <= v1) {
+      const u32x4_a4 r4 = {a0, a1, a2, a3};
+      *(PQD_GLOBAL u32x4_a4*)(out + g0) = r4;
+    } else if (g0 < v1) {
+      out[g0] = a0;
+      if (g0 + 1 < v1) out[g0 + 1] = a1;
+      if (g0 + 2 < v1) out[g0 + 2] = a2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restrict__ pool, uint32_t pool_chunks,
+                                                           const uint32_t* __restrict__ cursor,
+                                                           uint32_t* __restrict__ next_chunk) {
+  __shared__ RleSeg cs_buf[SEG_CHUNK];
+  __shared__ uint32_t s_chunk;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = uni(tid >> 6);
+  uint32_t n_chunks = *cursor;  // chunks the plan kernel allocated (it may have asked for more than there are)
+  if (n_chunks > pool_chunks) n_chunks = pool_chunks;
+  const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)cs_buf;
+  for (;;) {
+    __syncthreads();  // everybody is done with the previous chunk
+    if (tid == 0) s_chunk = atomicAdd(next_chunk, 1u);
+    __syncthreads();
+    const uint32_t c = s_chunk;
+    if (c >= n_chunks) break;
+    {
+      const PQD_GLOBAL uint64_t* src = (const PQD_GLOBAL uint64_t*)(pool + (size_t)c * SEG_CHUNK);
+      ((PQD_LDS uint64_t*)cs_buf)[tid] = src[tid];  // SEG_CHUNK == EX_THREADS slots of 8 bytes
+    }
+    __syncthreads();
+    const PQD_LDS RleChunkHead* hd = (const PQD_LDS RleChunkHead*)(cs + SEG_HEAD_SLOT);
+    const uint32_t dlo = uni((uint32_t)hd->data), dhi = uni((uint32_t)(hd->data >> 32));
+    const uint64_t data = ((uint64_t)dhi << 32) | dlo;
+    const uint64_t out_addr = ((uint64_t)uni((uint32_t)(hd->out >> 32)) << 32) | uni((uint32_t)hd->out);
+    const uint32_t v0 = uni(hd->v0), v1 = uni(hd->v1);
+    const uint32_t data_len = uni(hd->data_len), stream_end = uni(hd->stream_end);
+    ExHead h;
+    h.in_off = dlo & 3u;
+    h.words = (const PQD_GLOBAL uint32_t*)(data - h.in_off);
+    h.last_word = data_len ? (h.in_off + data_len - 1) >> 2 : 0u;
+    const uint32_t end_bytes = h.in_off + stream_end;
+    h.full_words = end_bytes >> 2;
+    h.tail_mask = (end_bytes & 3u) ? ((1u << (8 * (end_bytes & 3u))) - 1u) : 0u;
+    h.w = uni(hd->w);
+    PQD_GLOBAL uint32_t* out = (PQD_GLOBAL uint32_t*)out_addr;
+    if (h.w <= 16) {
+      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<false>(cs, h, v0, t0, v1, out, tid, wave);
+    } else {
+      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<true>(cs, h, v0, t0, v1, out, tid, wave);
+    }
+  }
+}
+
+static int g_ex_cu_count = 0;
+
+hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* next_chunk,
+                             hipStream_t stream) {
+  if (g_ex_cu_count == 0) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    g_ex_cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  hipLaunchKernelGGL(k_rle_expand, dim3((uint32_t)g_ex_cu_count * 8), dim3(EX_THREADS), 0, stream,
+                     reinterpret_cast<const RleSeg*>(pool), pool_chunks, cursor, next_chunk);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -33,20 +33,21 @@ struct PlanState {
   uint32_t need_round;  // the walk needs header bytes that the last round did not fetch
   uint32_t round_pos0;  // stream offset of block 0 of the last round
   uint32_t round_stride;
-  uint32_t next_stride; // length of the last run walked: stride of the next round
+  uint32_t next_stride; // length of the last run walked: stride of the next round ...
+  uint32_t prev_stride; // ... if the run before it had the same length (else the round is one contiguous KiB)
   uint32_t chunk_slot;  // pool chunk obtained for the flush in progress
 };
 
 // One lane.  Emits segments into `stage` until the stage is full, the walk leaves the header
 // window, or the page is finished.
 __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uint32_t w, uint32_t end,
-                          uint32_t n_values, uint32_t seg_groups_cap) {
+                          uint32_t n_values, uint32_t seg_groups_cap, uint32_t seg_limit) {
   uint32_t pos = st.pos, vals = st.vals, pending = st.pending, ns = st.nstage;
   const uint32_t pos0 = st.round_pos0, stride = st.round_stride;
-  uint32_t blk = 0, blk_pos = pos0, next_stride = st.next_stride;  // block that may hold the next header
+  uint32_t blk = 0, blk_pos = pos0, next_stride = st.next_stride, prev_stride = st.prev_stride;  // block that may hold the next header
   int32_t status = PQD_OK;
   bool need_round = false;
-  while (ns < (uint32_t)SEG_MAX + 1 && vals < n_values) {
+  while (ns < seg_limit && vals < n_values) {
     const uint32_t rem = n_values - vals;
     if (pending == 0) {
       if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
@@ -108,6 +109,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
         uint32_t value = 0;
         for (uint32_t i = 0; i < nbytes; ++i) value |= lds_byte(win, off + (p - run_pos) + i) << (8 * i);
         pos = p + nbytes;
+        prev_stride = next_stride;
         next_stride = pos - run_pos;
         // a zero-count run leaves currentCount negative: its value repeats for the rest of the page
         const uint32_t take = (count == 0 || count > rem) ? rem : count;
@@ -125,6 +127,7 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
       pending = groups;
       pos = p;
       const uint64_t run_len = (uint64_t)groups * w + (p - run_pos);
+      prev_stride = next_stride;
       next_stride = run_len > 0x40000000ull ? 0x40000000u : (uint32_t)run_len;
     }
     // ---- a piece of the current bit-packed run
@@ -178,6 +181,80 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
   st.nstage = ns;
   st.need_round = need_round ? 1u : 0u;
   st.next_stride = next_stride;
+  st.prev_stride = prev_stride;
+}
+
+// One fetch round (all lanes): lane l loads the 16 bytes at pos + l*stride into the header window
+// (bytes past the stream end read as zero).  When the stride is a run length (the last run walked
+// was a bit-packed run of `stride` bytes), the lanes then try the regular case in parallel: every
+// lane parses the header in its own block, and the leading lanes whose run is a full bit-packed
+// run of that same shape (same header bytes, same length, wholly inside the stream, all of its
+// values wanted) emit their segments at once.  Pages as parquet-java writes them (63-group runs
+// behind 1-byte headers) are planned 64 runs per round this way; anything else is left to the
+// serial walk, which starts where the regular prefix ends.
+__device__ __forceinline__ void plan_round(PlanState& st, u32x4* win4, RleSeg* stage, const uint8_t* data, uint32_t end,
+                                           uint32_t w, uint32_t n_values, uint32_t seg_limit, uint32_t tid) {
+  const uint32_t cur = st.pos;
+  const uint32_t stride = (st.next_stride >= 24 && st.next_stride == st.prev_stride) ? st.next_stride : 16u;
+  const uint64_t at = (uint64_t)cur + (uint64_t)tid * stride;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (at + 16 <= end) {
+    __builtin_memcpy(&v, data + at, 16);
+  } else if (at < end) {
+    uint32_t tmp[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t i = 0; i < (uint32_t)(end - at); ++i) tmp[i >> 2] |= (uint32_t)data[at + i] << (8 * (i & 3u));
+    v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+  }
+  const uint32_t vals = st.vals, ns = st.nstage, pending = st.pending;
+  __syncthreads();
+  win4[tid] = v;
+  if (tid == 0) {
+    win4[PLAN_SLOTS] = u32x4{0u, 0u, 0u, 0u};
+    st.round_pos0 = cur;
+    st.round_stride = stride;
+  }
+  // ---- the regular case
+  uint32_t m = 0;
+  if (stride >= 24 && pending == 0 && w > 0) {
+    // varint header in the first bytes of the block (at most 4 bytes here: longer ones go the serial way)
+    const uint32_t b0 = v.x & 0xFFu, b1 = (v.x >> 8) & 0xFFu, b2 = (v.x >> 16) & 0xFFu, b3 = v.x >> 24;
+    uint32_t header, nb;
+    if (!(b0 & 0x80u)) {
+      header = b0;
+      nb = 1;
+    } else if (!(b1 & 0x80u)) {
+      header = (b0 & 0x7Fu) | (b1 << 7);
+      nb = 2;
+    } else if (!(b2 & 0x80u)) {
+      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | (b2 << 14);
+      nb = 3;
+    } else {
+      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | ((b2 & 0x7Fu) << 14) | (b3 << 21);
+      nb = (b3 & 0x80u) ? 0u : 4u;
+    }
+    const uint32_t groups = header >> 1;
+    const uint32_t h0 = __builtin_amdgcn_readfirstlane(header), nb0 = __builtin_amdgcn_readfirstlane(nb);
+    const uint32_t g0 = h0 >> 1;
+    // lane 0 decides the shape; a lane fits if its run has that shape and lies inside the stream and the page
+    const bool shape = nb0 != 0 && (h0 & 1u) && g0 >= 1 && (uint64_t)g0 * w + nb0 == stride &&
+                       (uint64_t)g0 * w <= (uint64_t)PLAN_SEG_MAX_BYTES;
+    const bool fits = shape && header == h0 && nb == nb0 && groups == g0 && at + stride <= end &&
+                      (uint64_t)vals + (uint64_t)(tid + 1) * g0 * 8 <= n_values && ns + tid < seg_limit;
+    const uint64_t miss = ~__builtin_amdgcn_ballot_w64(fits);
+    m = miss ? (uint32_t)__builtin_ctzll(miss) : 64u;
+    if (tid < m) {
+      stage[ns + tid].start4 = ((vals + tid * g0 * 8) << 2) | SEG_PACKED_BIT;
+      stage[ns + tid].src = (uint32_t)at + nb0;
+    }
+    if (tid == 0 && m) {
+      st.pos = cur + m * stride;
+      st.vals = vals + m * g0 * 8;
+      st.nstage = ns + m;
+      if (st.vals >= n_values) st.done = 1;
+    }
+  }
+  if (tid == 0) st.need_round = (m == 64u) ? 1u : 0u;  // a whole round of regular runs: the next one starts past it
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* __restrict__ descs,
@@ -272,6 +349,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     st.round_pos0 = pos;
     st.round_stride = 16;
     st.next_stride = 16;
+    st.prev_stride = 16;
     st.chunk_slot = 0;
   }
   __syncthreads();
@@ -280,29 +358,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
   uint32_t nseg = 0;
   bool fallback = false;
   for (;;) {
-    if (st.need_round) {
-      // one round: lane l fetches the 16 bytes at pos + l*stride (bytes past the stream end read as zero)
-      const uint32_t cur = st.pos;
-      const uint32_t stride = st.next_stride < 24 ? 16u : st.next_stride;
-      const uint64_t at = (uint64_t)cur + (uint64_t)tid * stride;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (at + 16 <= end) {
-        __builtin_memcpy(&v, d.data + at, 16);
-      } else if (at < end) {
-        uint32_t tmp[4] = {0u, 0u, 0u, 0u};
-        for (uint32_t i = 0; i < (uint32_t)(end - at); ++i) tmp[i >> 2] |= (uint32_t)d.data[at + i] << (8 * (i & 3u));
-        v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
-      }
-      __syncthreads();
-      win4[tid] = v;
-      if (tid == 0) {
-        win4[PLAN_SLOTS] = u32x4{0u, 0u, 0u, 0u};
-        st.round_pos0 = cur;
-        st.round_stride = stride;
-      }
-      __syncthreads();
-    }
-    if (tid == 0) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap);
+    if (st.need_round) plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
+    if (tid == 0 && !st.need_round && !st.done) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_MAX + 1);
     __syncthreads();
     const uint32_t ns = st.nstage;
     const bool done = st.done != 0;
@@ -368,6 +425,227 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
     pl.dict_len = d.dict_len;
     plans[page] = pl;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same walk for plain hybrid pages (PQD_ENC_RLE: levels, booleans, ids as ints) of any length:
+// the plan is a list of chunks taken from a shared pool (pqd_rle_plan.hpp), consumed by
+// k_rle_expand.  The page's result is final here (nothing downstream can fail).
+__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page_desc* __restrict__ descs,
+                                                                  pqd_page_result* __restrict__ results,
+                                                                  RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
+                                                                  uint32_t pool_chunks, uint32_t* __restrict__ cursor,
+                                                                  uint32_t n_pages) {
+  __shared__ u32x4 win4[PLAN_SLOTS + 1];
+  __shared__ RleSeg stage[SEG_CHUNK];
+  __shared__ RleSeg chunk[SEG_CHUNK];
+  __shared__ PlanState st;
+  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_page_desc d = descs[page];
+  const uint32_t tid = threadIdx.x;
+
+  // ---- validation and stream prefixes (same rules as the generic kernel)
+  int32_t early = PQD_OK;
+  bool finished = false;
+  uint32_t pos = 0, end = d.data_len, w = d.bit_width, consumed_override = ~0u;
+  const uint32_t n_values = d.num_values;
+  if (d.encoding != PQD_ENC_RLE || d.elem_size != 4) {
+    early = PQD_BAD_ARG;
+    finished = true;
+  } else if (d.flags & PQD_F_WIDTH_PREFIX) {
+    if (end == 0) {
+      early = n_values ? PQD_DECODE : PQD_OK;
+      finished = true;
+    } else {
+      w = d.data[0];
+      pos = 1;
+    }
+  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
+    if (end < 4) {
+      early = PQD_EOF;
+      finished = true;
+    } else {
+      const uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) |
+                           ((uint32_t)d.data[3] << 24);
+      if ((int32_t)len < 0) {
+        early = PQD_DECODE;
+        finished = true;
+      } else if (len > end - 4) {
+        early = PQD_EOF;
+        finished = true;
+      } else {
+        pos = 4;
+        end = 4 + len;
+        consumed_override = end;
+      }
+    }
+  }
+  if (!finished && w > 32) {
+    early = PQD_BAD_ARG;
+    finished = true;
+  }
+  if (finished || n_values == 0) {
+    if (tid == 0) {
+      pqd_page_result r;
+      r.status = early;
+      r.values_written = 0;
+      r.bytes_consumed = early == PQD_OK ? (consumed_override != ~0u ? consumed_override : pos) : 0;
+      r.reserved = 0;
+      results[page] = r;
+      RlePagePlan pl = {};
+      pl.status = early;
+      pl.flags = PLAN_F_DONE;
+      plans[page] = pl;
+    }
+    return;
+  }
+  if (n_values > SEG_START_MAX) {  // segment start indices hold 30 bits
+    if (tid == 0) {
+      RlePagePlan pl = {};
+      pl.flags = PLAN_F_FALLBACK;
+      plans[page] = pl;
+    }
+    return;
+  }
+  if (tid == 0) {
+    st.pos = pos;
+    st.vals = 0;
+    st.pending = 0;
+    st.nstage = 0;
+    st.status = PQD_OK;
+    st.done = 0;
+    st.need_round = 1;
+    st.round_pos0 = pos;
+    st.round_stride = 16;
+    st.next_stride = 16;
+    st.prev_stride = 16;
+    st.chunk_slot = 0;
+  }
+  __syncthreads();
+
+  const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
+  uint32_t v0 = 0;  // start of the chunk being collected
+  bool fallback = false;
+  for (;;) {
+    if (st.need_round) plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
+    if (tid == 0 && !st.need_round && !st.done) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_GEN_MAX);
+    __syncthreads();
+    const bool done = st.done != 0;
+    const uint32_t vals = st.vals;
+    uint32_t ns = st.nstage;
+    // ---- cut chunks off the front of the stage while there is reason to
+    while (!fallback && (done ? v0 < vals : (ns >= (uint32_t)SEG_GEN_MAX || vals - v0 >= SEG_CHUNK_SPAN))) {
+      uint32_t v1 = vals - v0 > SEG_CHUNK_SPAN ? v0 + SEG_CHUNK_SPAN : vals;
+      if (!(done && v1 == vals)) v1 &= ~(uint32_t)(SEG_BLOCK - 1);
+      if (v1 <= v0) {  // more than SEG_GEN_MAX runs inside one block of values: not for this path
+        fallback = true;
+        break;
+      }
+      // k = staged segments that start before v1 (the stage is sorted by start)
+      uint32_t k = 0;
+      {
+        uint32_t lo = 0, hi = ns;  // start[lo] < v1 (segment 0 starts at or before v0), start[hi] >= v1
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((stage[mid].start4 >> 2) < v1)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        k = hi;
+      }
+      if (tid == 0) {
+        uint32_t slot = atomicAdd(cursor, 1u);
+        st.chunk_slot = slot < pool_chunks ? slot : ~0u;
+      }
+      __syncthreads();
+      const uint32_t slot = st.chunk_slot;
+      if (slot == ~0u) {
+        fallback = true;
+        break;
+      }
+      for (uint32_t i = tid; i < k; i += PLAN_THREADS) chunk[i] = stage[i];
+      if (tid == 0) {
+        chunk[k].start4 = v1 << 2;  // sentinel
+        chunk[k].src = 0;
+        RleChunkHead* hd = reinterpret_cast<RleChunkHead*>(chunk + SEG_HEAD_SLOT);
+        hd->data = (uint64_t)(uintptr_t)d.data;
+        hd->out = (uint64_t)(uintptr_t)d.out;
+        hd->v0 = v0;
+        hd->v1 = v1;
+        hd->nseg = k;
+        hd->w = w;
+        hd->data_len = d.data_len;
+        hd->stream_end = end;
+        hd->page = page;
+      }
+      __syncthreads();
+      uint8_t* table = reinterpret_cast<uint8_t*>(chunk + SEG_TABLE_SLOT);
+      for (uint32_t b = tid; b < (uint32_t)SEG_TABLE_BLOCKS; b += PLAN_THREADS) {
+        const uint32_t first = v0 + b * SEG_BLOCK;
+        uint32_t lo = 0, hi = k;  // start[lo] <= first < start[hi]
+        if (first >= v1) {
+          lo = k - 1;
+        } else {
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((chunk[mid].start4 >> 2) <= first)
+              lo = mid;
+            else
+              hi = mid;
+          }
+        }
+        table[b] = (uint8_t)lo;
+      }
+      __syncthreads();
+      {
+        const u32x4* src = reinterpret_cast<const u32x4*>(chunk);
+        u32x4* dst = reinterpret_cast<u32x4*>(pool + (size_t)slot * SEG_CHUNK);
+        for (uint32_t i = tid; i < (k + 2) / 2; i += PLAN_THREADS) dst[i] = src[i];                    // segments + sentinel
+        for (uint32_t i = SEG_HEAD_SLOT / 2 + tid; i < (uint32_t)SEG_CHUNK / 2; i += PLAN_THREADS) dst[i] = src[i];  // header + table
+      }
+      // what stays staged: the segments from v1 on, led by the last one cut if it reaches past v1
+      const uint32_t next_start = k < ns ? stage[k].start4 >> 2 : vals;
+      const uint32_t j0 = next_start > v1 ? k - 1 : k;
+      const uint32_t left = ns - j0;
+      for (uint32_t base = 0; base < left; base += PLAN_THREADS) {
+        RleSeg t = {0u, 0u};
+        if (base + tid < left) t = stage[j0 + base + tid];
+        __syncthreads();
+        if (base + tid < left) stage[base + tid] = t;
+        __syncthreads();
+      }
+      ns = left;
+      v0 = v1;
+    }
+    __syncthreads();
+    if (tid == 0) st.nstage = ns;
+    __syncthreads();
+    if (done || fallback) break;
+  }
+  if (tid == 0) {
+    RlePagePlan pl = {};
+    pl.flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
+    plans[page] = pl;
+    if (!fallback) {
+      pqd_page_result r;
+      r.status = st.status;
+      r.values_written = st.vals;
+      r.bytes_consumed = consumed_override != ~0u ? consumed_override : st.pos;
+      r.reserved = 0;
+      results[page] = r;
+    }
+  }
+}
+
+hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
+                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
+                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages);
+  return hipGetLastError();
 }
 
 hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,

@@ -76,8 +76,11 @@ int check_device_available() {
 // share it.  Grown on demand, never shrunk, released with the process.
 struct PlanScratch {
   void* plans = nullptr;
-  void* pool = nullptr;
+  void* pool = nullptr;        // dictionary path: chunk p belongs to page p
   uint32_t cap_pages = 0;
+  void* gen_pool = nullptr;    // plain hybrid pages: chunks handed out through counters[0]
+  uint32_t gen_chunks = 0;
+  uint32_t* counters = nullptr;  // [0] chunks allocated by the plan kernel, [1] chunks taken by the expansion kernel
 };
 std::mutex g_plan_mutex;
 std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
@@ -99,6 +102,31 @@ int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
     PQD_HIP(hipMalloc(&ps.pool, (size_t)pages * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
     ps.cap_pages = pages;
   }
+  *out = ps;
+  return PQD_OK;
+}
+
+// The same, plus the chunk pool of the plain hybrid path: two chunks per page and a shared reserve
+// (a 20000-value level page needs 1-6 chunks, a 1 M-value page about 31; a page that finds the pool
+// empty is decoded by the generic kernel).
+int plan_scratch_general(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
+  int st = plan_scratch_for(stream, n_pages, out);
+  if (st) return st;
+  int dev = 0;
+  PQD_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  PlanScratch& ps = g_plan_scratch[std::make_pair(dev, (void*)stream)];
+  const uint64_t want = (uint64_t)n_pages * 2 + 16384;
+  if (ps.gen_chunks < want) {
+    PQD_HIP(hipStreamSynchronize(stream));
+    if (ps.gen_pool) (void)hipFree(ps.gen_pool);
+    ps.gen_pool = nullptr;
+    ps.gen_chunks = 0;
+    const uint64_t chunks = want + want / 4;
+    PQD_HIP(hipMalloc(&ps.gen_pool, (size_t)chunks * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
+    ps.gen_chunks = (uint32_t)(chunks > 0xFFFFFFFFull ? 0xFFFFFFFFull : chunks);
+  }
+  if (!ps.counters) PQD_HIP(hipMalloc((void**)&ps.counters, 256));
   *out = ps;
   return PQD_OK;
 }
@@ -142,6 +170,12 @@ int phase_mark(int i, hipStream_t s) {
 // for the single generic kernel.  Read on every call so that a test can switch inside one process.
 bool use_sliced_dictionary_path() {
   const char* v = getenv("PQD_DICT_PATH");
+  return !(v && strcmp(v, "generic") == 0);
+}
+
+// The same switch for plain hybrid pages: PQD_RLE_PATH=generic selects the single generic kernel.
+bool use_planned_rle_path() {
+  const char* v = getenv("PQD_RLE_PATH");
   return !(v && strcmp(v, "generic") == 0);
 }
 
@@ -366,7 +400,20 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
   switch (encoding) {
     case PQD_ENC_RLE:
       if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_RLE produces 4-byte values");
-      PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, nullptr, s));
+      if (!use_planned_rle_path()) {
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, nullptr, s));
+      } else {
+        // 1. header walk of every page -> chunks of run segments in the pool
+        // 2. expansion of all chunks (workgroups take chunks from a counter)
+        // 3. generic kernel for the pages the plan left over
+        PlanScratch ps;
+        int st = plan_scratch_general(s, n_pages, &ps);
+        if (st) return st;
+        PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, s));
+        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, ps.gen_chunks, ps.counters, ps.counters + 1, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, s));
+      }
       return PQD_OK;
     case PQD_ENC_RLE_DICTIONARY:
       if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");

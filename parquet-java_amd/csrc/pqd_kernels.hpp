@@ -20,6 +20,11 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
 // pool_chunks chunks of 128 segments of 12 bytes, `pool_cursor` a zeroed counter
 hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                            uint32_t n_pages, bool want_dict, int elem, hipStream_t stream);
+// plain hybrid pages: header walk into pool chunks, then expansion of all chunks
+hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
+                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, hipStream_t stream);
+hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* next_chunk,
+                             hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather
 hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
                                     const void* pool, uint32_t n_pages, int elem, hipStream_t stream);

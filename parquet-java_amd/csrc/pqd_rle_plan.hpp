@@ -34,6 +34,27 @@ constexpr int SEG_BLOCK = 256;
 constexpr int SEG_TABLE_BLOCKS = (SEG_CHUNK - SEG_TABLE_SLOT) * 8;  // 128 blocks = 32768 values
 constexpr int PLAN_SEG_MAX_BYTES = 6144;  // payload bytes of one bit-packed segment
 
+// Plain hybrid pages (levels, ids, booleans) of any length are planned as a list of such chunks,
+// each covering the output values [v0, v1) of one page: v0 and v1 are multiples of SEG_BLOCK (v1
+// may also be the page's end), the first segment may begin before v0, the sentinel's start is v1,
+// table block b starts at value v0 + b * SEG_BLOCK, and the chunk carries its own header:
+constexpr int SEG_HEAD_SLOT = 232;               // slots 232..239: RleChunkHead
+constexpr int SEG_GEN_MAX = SEG_HEAD_SLOT - 1;   // segments per chunk of the general path
+constexpr uint32_t SEG_CHUNK_SPAN = SEG_TABLE_BLOCKS * SEG_BLOCK;  // values per chunk, at most
+
+struct RleChunkHead {
+  uint64_t data;        // the page's stream
+  uint64_t out;         // the page's output (element 0)
+  uint32_t v0, v1;      // output values covered
+  uint32_t nseg;
+  uint32_t w;
+  uint32_t data_len;
+  uint32_t stream_end;  // bytes at or past it read as zero
+  uint32_t page;
+  uint32_t reserved[5];
+};
+static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
+
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
 constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel
 

@@ -26,3 +26,10 @@ def dict_path(request, monkeypatch):
     every call; monkeypatch.setenv reaches the C library's getenv through os.putenv)."""
     monkeypatch.setenv("PQD_DICT_PATH", request.param)
     return request.param
+
+
+@pytest.fixture(params=["generic", "planned"])
+def rle_path(request, monkeypatch):
+    """Runs a test once per kernel path of plain hybrid pages (PQD_RLE_PATH, read on every call)."""
+    monkeypatch.setenv("PQD_RLE_PATH", request.param)
+    return request.param

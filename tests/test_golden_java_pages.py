@@ -41,7 +41,7 @@ def test_oracle_decodes_java_written_pages(orc):
 
 
 @pytest.mark.gpu
-def test_gpu_decodes_java_written_pages(orc, dict_path):
+def test_gpu_decodes_java_written_pages(orc, dict_path, rle_path):
     import parquet_java_amd as pq
     import gpu_harness as gh
     pq.init(0)

@@ -92,7 +92,7 @@ def check_rle(gpu, orc, cases, elem=4):
         assert (guard == 0xA5).all(), "wrote past the output"
 
 
-def test_rle_integration_pattern_all_widths(gpu, orc):
+def test_rle_integration_pattern_all_widths(gpu, orc, rle_path):
     from test_oracle_kat import integration_pattern
     cases = []
     for w in range(0, 33):
@@ -102,7 +102,7 @@ def test_rle_integration_pattern_all_widths(gpu, orc):
     check_rle(gpu, orc, cases)
 
 
-def test_rle_known_answer_and_quirks(gpu, orc):
+def test_rle_known_answer_and_quirks(gpu, orc, rle_path):
     import parquet_java_amd as pq
     kat = bytes([(1 << 1) | 1, (1 << 0) | (2 << 2) | (3 << 4)])
     cases = [
@@ -128,7 +128,7 @@ def test_rle_known_answer_and_quirks(gpu, orc):
     check_rle(gpu, orc, cases)
 
 
-def test_rle_random_mixed_runs(gpu, orc):
+def test_rle_random_mixed_runs(gpu, orc, rle_path):
     rng = np.random.default_rng(5)
     cases = []
     for w in (1, 2, 3, 5, 8, 9, 12, 16, 17, 24, 31, 32):
@@ -147,7 +147,7 @@ def test_rle_random_mixed_runs(gpu, orc):
     check_rle(gpu, orc, cases)
 
 
-def test_rle_large_pages_cross_windows(gpu, orc):
+def test_rle_large_pages_cross_windows(gpu, orc, rle_path):
     rng = np.random.default_rng(9)
     cases = []
     for w, n in ((32, 60_000), (20, 300_000), (1, 1_000_000), (13, 1_000_000)):
@@ -169,12 +169,51 @@ def test_rle_large_pages_cross_windows(gpu, orc):
     check_rle(gpu, orc, cases)
 
 
-def test_rle_many_tiny_runs(gpu, orc):
+def test_rle_many_tiny_runs(gpu, orc, rle_path):
     # more runs than one segment table holds: count-1 RLE runs and 1-group packed runs
     data = bytearray()
     for i in range(3000):
         data += bytes([2, i & 0xFF]) if i % 2 else bytes([3, i & 0xFF])
     check_rle(gpu, orc, [(8, bytes(data), 1500 + 1500 * 8, 0), (8, bytes(data), 7001, 0)])
+
+
+def test_rle_many_pages_all_widths(gpu, orc, rle_path):
+    """Hundreds of hybrid pages in one launch: every width 0..32, run boundaries off multiples of
+    four, pages from one value to several chunks of the plan, length-prefixed and width-prefixed
+    streams, streams cut short."""
+    import parquet_java_amd as pq
+    rng = np.random.default_rng(99)
+    pages, expect = [], []
+    for i in range(500):
+        w = int(rng.integers(0, 33))
+        n = int(rng.choice([1, 5, 8, 255, 256, 257, 4095, 4096, 20000, 32768, 32769, 70001])) if i % 2 else int(rng.integers(1, 50000))
+        vals = np.empty(n, np.int64)
+        pos = 0
+        mean_run = int(rng.choice([1, 3, 9, 40, 600]))
+        while pos < n:
+            ln = min(n - pos, int(rng.geometric(1.0 / mean_run)))
+            vals[pos:pos + ln] = rng.integers(0, 1 << w) if rng.random() < 0.5 else rng.integers(0, 1 << w, ln)
+            pos += ln
+        body = bytes(orc.rle_encode(w, vals.astype(np.uint32).view(np.int32)))
+        kind = i % 5
+        if i % 31 == 0 and len(body) > 2:
+            body = body[:len(body) - int(rng.integers(1, min(len(body), 30)))]  # stream cut short
+        if kind == 0:
+            data, flags, bw = len(body).to_bytes(4, "little") + body + b"\x99\x98", pq.F_LENGTH_PREFIX, w
+            ost, ovals, oused = orc.rle_decode(w, data, n, prefixed=True)
+        elif kind == 1:
+            data, flags, bw = bytes([w]) + body, pq.F_WIDTH_PREFIX, 0
+            ost, ovals = orc.dict_decode_ids(data, n)
+        else:
+            data, flags, bw = body, 0, w
+            ost, ovals, oused = orc.rle_decode(w, body, n)
+        pages.append(gpu.Page(data, n, pq.ENC_RLE, 4, bit_width=bw, flags=flags))
+        expect.append((ost, ovals, kind))
+    res = gpu.decode_pages(pages)
+    for i, ((st, written, consumed, out, guard), (ost, ovals, kind)) in enumerate(zip(res, expect)):
+        assert st == ost and written == ovals.size, (i, kind, st, ost, written, ovals.size, pages[i].num_values)
+        assert (out.view(np.int32)[:written] == ovals).all(), (i, kind)
+        assert (guard == 0xA5).all(), i
 
 
 # ------------------------------------------------------------------------------- dictionary

@@ -34,8 +34,13 @@ def timeit(fn, iters=10, warm=3):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+ONLY = os.environ.get("KR_ONLY", "")
+
+
 def run_pages(label, distinct, copies, n_values, encoding, elem, bit_width=0, flags=0, dictionary=None):
     """distinct: list of page byte strings; the batch holds each `copies` times."""
+    if ONLY and ONLY not in label:
+        return
     pages = [np.frombuffer(bytes(p), np.uint8) for p in distinct] * copies
     offs, pos = [], 0
     for p in pages:
@@ -67,6 +72,8 @@ def main():
     # raw bit-packed runs (the ParquetReadRouter contract)
     n = 1 << 28
     for w, long in ((8, False), (16, False), (12, True)):
+        if ONLY:
+            break
         nb = n * w // 8
         src = torch.randint(0, 256, (nb,), dtype=torch.uint8, device=DEV)
         dst = torch.empty(n, dtype=torch.int64 if long else torch.int32, device=DEV)
