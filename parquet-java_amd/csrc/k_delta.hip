@@ -27,6 +27,12 @@ constexpr int DWINDOW_SLACK = 48;
 constexpr int DWINDOW_PIECES = (DWINDOW_BYTES + DWINDOW_SLACK) / 16;
 constexpr int MAX_MINIS = 1024;      // miniblock table entries per window
 constexpr int MAX_MINI_PER_BLOCK = 256;
+constexpr int MAX_FAST_BLOCKS = DELTA_THREADS;  // blocks per window whose headers are expanded one per lane
+
+#define PQD_LDS __attribute__((address_space(3)))
+typedef const PQD_LDS uint32_t* lds_words_t;
+
+__device__ __forceinline__ uint32_t ldsb(lds_words_t w, uint32_t off) { return (w[off >> 2] >> ((off & 3u) * 8u)) & 0xFFu; }
 
 struct DeltaState {
   uint32_t pos;           // next unread stream byte
@@ -40,15 +46,18 @@ struct DeltaState {
   uint32_t block_size, mini_n, mini_size, total;
   uint64_t first;
   uint64_t min_delta;     // of the current block
+  uint32_t fast_blocks;   // whole blocks found by the quick walk in the current window ...
+  uint32_t fast_take;     // ... and the miniblocks of the last of them (the others have mini_n)
+  uint32_t fast_base;     // table index of their first miniblock
 };
 
-__device__ __forceinline__ bool lds_varint(const uint32_t* win, int32_t base, uint32_t& p, uint32_t end,
+__device__ __forceinline__ bool lds_varint(lds_words_t win, int32_t base, uint32_t& p, uint32_t end,
                                            uint64_t& out, bool is_long) {
   uint64_t v = 0;
   uint32_t shift = 0;
   for (int i = 0; i < 12; ++i) {
     if (p >= end) return false;
-    uint64_t b = lds_byte(win, p - base);
+    uint64_t b = ldsb(win, p - base);
     ++p;
     uint32_t s = is_long ? (shift & 63u) : (shift & 31u);
     if (b & 0x80u) {
@@ -78,8 +87,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   __shared__ uint64_t mini_min[MAX_MINIS];
   __shared__ uint8_t cur_widths[MAX_MINI_PER_BLOCK];
   __shared__ acc_t wave_sum[DELTA_THREADS / 64];
+  __shared__ uint32_t blk_off[MAX_FAST_BLOCKS];  // window offset of the block headers found by the quick walk
   __shared__ DeltaState st;
-  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
+  lds_words_t win = (lds_words_t)(const PQD_LDS u32x4*)win4;
 
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -167,8 +177,10 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       uint64_t min_delta = st.min_delta;
       int32_t status = PQD_OK;
       const uint32_t mini_bytes_unit = mini_size >> 3;
-      while (nm < MAX_MINIS && scanned < n_deltas) {
+      auto careful_walk = [&](bool only_current_block) {
+      while (nm < MAX_MINIS && scanned < n_deltas && status == PQD_OK) {
         if (left == 0) {
+          if (only_current_block) break;
           if (nm > 0 && wend < end && p + 12 + st.mini_n > wend) break;  // header may straddle: restage
           uint64_t raw;
           if (!lds_varint(win, base, p, end, raw, true)) {
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
             status = PQD_DECODE;  // "Can not decode bitwidth in block header"
             break;
           }
-          for (uint32_t i = 0; i < st.mini_n; ++i) cur_widths[i] = (uint8_t)lds_byte(win, p - base + i);
+          for (uint32_t i = 0; i < st.mini_n; ++i) cur_widths[i] = (uint8_t)ldsb(win, p - base + i);
           p += st.mini_n;
           const uint32_t need = (n_deltas - scanned + mini_size - 1) / mini_size;
           left = need < st.mini_n ? need : st.mini_n;
@@ -209,6 +221,48 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
         ++cm;
         --left;
       }
+      };
+      careful_walk(true);  // the rest of a block that the previous window cut
+      const uint32_t fast_base = nm;
+      // Quick walk over whole blocks (lane 0 only finds where they start; their headers are expanded
+      // into the miniblock table by one lane per block below).  It reads 16 bytes per block, takes
+      // the length of the min-delta varint from its continuation bits and adds up the width bytes.
+      // Anything unusual (more than 8 miniblocks per block, a varint longer than 8 bytes, a width
+      // above 64, the end of the stream or of the window in sight) ends it, and the careful walk
+      // below carries on from that block and reports what is wrong with it.
+      uint32_t nblk = 0, last_take = st.mini_n;
+      if (left == 0 && st.mini_n <= 8 && status == PQD_OK) {
+        const uint32_t mn = st.mini_n;
+        while (nm + mn <= MAX_MINIS && nblk < (uint32_t)MAX_FAST_BLOCKS && scanned < n_deltas) {
+          if (p + 16 > end || p + 16 > wend) break;
+          const uint32_t off = (uint32_t)(p - base), i0 = off >> 2, sh = (off & 3u) * 8u;
+          const uint32_t a0 = win[i0], a1 = win[i0 + 1], a2 = win[i0 + 2], a3 = win[i0 + 3], a4 = win[i0 + 4];
+          const uint32_t b0 = funnel_shr(a0, a1, sh), b1 = funnel_shr(a1, a2, sh), b2 = funnel_shr(a2, a3, sh),
+                         b3 = funnel_shr(a3, a4, sh);
+          const uint64_t lo = ((uint64_t)b1 << 32) | b0, hi = ((uint64_t)b3 << 32) | b2;
+          const uint64_t stop = ~lo & 0x8080808080808080ull;  // bytes without the continuation bit
+          if (!stop) break;
+          const uint32_t nbv = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1;  // 1..8 bytes of min delta
+          const uint64_t wbytes = nbv == 8 ? hi : ((lo >> (8 * nbv)) | (hi << (64 - 8 * nbv)));
+          const uint32_t need = (n_deltas - scanned + mini_size - 1) / mini_size;
+          const uint32_t take = need < mn ? need : mn;
+          const uint64_t used = take == 8 ? wbytes : (wbytes & ((1ull << (8 * take)) - 1ull));
+          if ((used & 0x8080808080808080ull) || ((used + 0x3F3F3F3F3F3F3F3Full) & 0x8080808080808080ull)) break;  // a width > 64
+          const uint32_t wsum = __builtin_amdgcn_sad_u8((uint32_t)used, 0u, __builtin_amdgcn_sad_u8((uint32_t)(used >> 32), 0u, 0u));
+          const uint32_t pay = p + nbv + mn, bytes = mini_bytes_unit * wsum;
+          if (end - pay < bytes || pay + bytes > wend) break;
+          blk_off[nblk] = off;
+          ++nblk;
+          last_take = take;
+          nm += take;
+          p = pay + bytes;
+          scanned += take * mini_size;
+        }
+      }
+      st.fast_blocks = nblk;
+      st.fast_take = last_take;
+      st.fast_base = fast_base;
+      careful_walk(false);
       st.pos = p;
       st.window_minis = nm;
       st.minis_left = left;
@@ -223,6 +277,35 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
     }
     __syncthreads();
     first_window = false;
+    // one lane per block found by the quick walk: min delta, widths -> miniblock table entries
+    {
+      const uint32_t nblk = st.fast_blocks, mn = st.mini_n;
+      if (tid < nblk) {
+        const uint32_t off = blk_off[tid];
+        uint32_t q = off;
+        uint64_t raw = 0;
+        uint32_t shift = 0;
+        for (int i = 0; i < 8; ++i) {  // the quick walk made sure the varint ends within 8 bytes
+          const uint64_t b = ldsb(win, q);
+          ++q;
+          raw |= (b & 0x7Fu) << shift;
+          shift += 7;
+          if (!(b & 0x80u)) break;
+        }
+        const uint64_t md = (uint64_t)zigzag64(raw);
+        const uint32_t take = tid + 1 == nblk ? st.fast_take : mn;
+        uint32_t src = q + mn;
+        for (uint32_t i = 0; i < take; ++i) {
+          const uint32_t w = ldsb(win, q + i);
+          const uint32_t e = st.fast_base + tid * mn + i;
+          mini_src[e] = src;
+          mini_w[e] = w;
+          mini_min[e] = md;
+          src += (mini_size >> 3) * w;
+        }
+      }
+      __syncthreads();
+    }
     if (st.status != PQD_OK) break;
 
     // ---- 3. unpack + running sum, 1024 deltas per tile
