@@ -185,33 +185,58 @@ __device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t 
                                              uint32_t wave, UnitRaw (&raw)[UNITS] PROF_FN_PARAM) {
   const PQD_LDS uint8_t* table = (const PQD_LDS uint8_t*)(cs + SEG_TABLE_SLOT);
   const uint32_t t1x4 = t1 << 2;
-  uint32_t wi[UNITS];
+  // Every step below is done for all units before the next one, so that a step costs one LDS
+  // round trip for the lane, not one per unit.
+  uint32_t sg[UNITS], wi[UNITS];
+  // the unit row of a wave is one block of the table; from its first segment walk forward
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) sg[k] = table[(uint32_t)k * (DS_THREADS * 4 / SEG_BLOCK) + wave];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    uint32_t nx[UNITS];
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const uint32_t g4 = 16 * ((uint32_t)k * DS_THREADS + tid) + 3;  // start4 <= g4  <=>  start <= g0
+      sg[k] += nx[k] <= g4 ? 1u : 0u;                                 // valid lanes stop at the sentinel
+    }
+  }
+  for (;;) {  // rare: more than two segment boundaries inside 256 values
+    bool any = false;
+    uint32_t nx[UNITS];
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+      const bool adv = g0 < t1 && nx[k] <= g0 * 4 + 3;
+      sg[k] += adv ? 1u : 0u;
+      any |= adv;
+    }
+    if (!__builtin_amdgcn_ballot_w64(any)) break;
+  }
+  uint32_t sk[UNITS], srcs[UNITS], e4s[UNITS];
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) {
+    sk[k] = cs[sg[k]].start4;
+    srcs[k] = cs[sg[k]].src;
+    e4s[k] = cs[sg[k] + 1].start4;
+  }
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
     const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
-    const uint32_t g4 = g0 * 4 + 3;  // start4 <= g4  <=>  start <= g0
-    // the unit row of a wave is one block of the table; from its first segment walk forward
-    uint32_t sg = uni(table[(uint32_t)k * (DS_THREADS * 4 / SEG_BLOCK) + wave]);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) sg += cs[sg + 1].start4 <= g4 ? 1u : 0u;  // valid lanes stop at the sentinel
-    for (;;) {  // rare: more than two segment boundaries inside 256 values
-      const bool adv = g0 < t1 && cs[sg + 1].start4 <= g4;
-      if (!__builtin_amdgcn_ballot_w64(adv)) break;
-      sg += adv ? 1u : 0u;
-    }
-    const uint32_t sk = cs[sg].start4, src = cs[sg].src;
-    const uint32_t e4 = cs[sg + 1].start4;
-    const uint32_t lim4 = e4 < t1x4 ? e4 : t1x4;
-    const bool is_packed = (sk & SEG_PACKED_BIT) != 0;
-    const bool whole = g0 * 4 + 16 <= lim4 && !(sk & SEG_PARTIAL_BIT);
+    const uint32_t lim4 = e4s[k] < t1x4 ? e4s[k] : t1x4;
+    const bool is_packed = (sk[k] & SEG_PACKED_BIT) != 0;
+    const bool whole = g0 * 4 + 16 <= lim4 && !(sk[k] & SEG_PARTIAL_BIT);
     // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
-    const uint32_t byte0 = h.in_off + src;
-    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk >> 2)) * h.w;
+    const uint32_t byte0 = h.in_off + srcs[k];
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk[k] >> 2)) * h.w;
     const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
     const bool fast = whole && is_packed && !h.no_fast && w_i <= h.max_wi;
     const uint32_t kind = g0 >= t1 ? UK_NONE : (is_packed ? (fast ? UK_PACKED : UK_SLOW) : (whole ? UK_RLE : UK_SLOW));
     wi[k] = kind == UK_PACKED ? w_i : 0u;
-    raw[k].meta = (bitrel & 31u) | (kind << 8) | (sg << 16);
+    raw[k].meta = (bitrel & 31u) | (kind << 8) | (sg[k] << 16);
   }
   PROF(11)
 #pragma unroll

@@ -61,32 +61,57 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
   const bool can_load = h.last_word + 1 >= (uint32_t)NW;  // the page holds at least one whole unit load
   const uint32_t max_wi = can_load ? h.last_word + 1 - NW : 0u;
   uint32_t wi[EX_UNITS], meta[EX_UNITS], other[EX_UNITS];
+  // Every step below is done for all units before the next one, so that a step costs one LDS
+  // round trip for the lane, not one per unit.
+  uint32_t sg[EX_UNITS];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) sg[k] = table[((t0 - v0) >> 8) + (uint32_t)k * (EX_THREADS * 4 / SEG_BLOCK) + wave];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    uint32_t nx[EX_UNITS];
+#pragma unroll
+    for (int k = 0; k < EX_UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
+#pragma unroll
+    for (int k = 0; k < EX_UNITS; ++k) {
+      const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+      sg[k] += nx[k] <= g0 * 4 + 3 ? 1u : 0u;  // start4 <= g0*4+3 <=> start <= g0; valid lanes stop at the sentinel
+    }
+  }
+  for (;;) {  // rare: more than two segment boundaries inside 256 values
+    bool any = false;
+    uint32_t nx[EX_UNITS];
+#pragma unroll
+    for (int k = 0; k < EX_UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
+#pragma unroll
+    for (int k = 0; k < EX_UNITS; ++k) {
+      const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+      const bool adv = g0 < v1 && nx[k] <= g0 * 4 + 3;
+      sg[k] += adv ? 1u : 0u;
+      any |= adv;
+    }
+    if (!__builtin_amdgcn_ballot_w64(any)) break;
+  }
+  uint32_t sk[EX_UNITS], e4s[EX_UNITS];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    sk[k] = cs[sg[k]].start4;
+    other[k] = cs[sg[k]].src;  // stream offset of a bit-packed segment / the repeated value of an RLE run
+    e4s[k] = cs[sg[k] + 1].start4;
+  }
 #pragma unroll
   for (int k = 0; k < EX_UNITS; ++k) {
     const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
-    const uint32_t g4 = g0 * 4 + 3;  // start4 <= g4  <=>  start <= g0
-    uint32_t sg = uni(table[((t0 - v0) >> 8) + (uint32_t)k * (EX_THREADS * 4 / SEG_BLOCK) + wave]);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) sg += cs[sg + 1].start4 <= g4 ? 1u : 0u;  // valid lanes stop at the sentinel
-    for (;;) {  // rare: more than two segment boundaries inside 256 values
-      const bool adv = g0 < v1 && cs[sg + 1].start4 <= g4;
-      if (!__builtin_amdgcn_ballot_w64(adv)) break;
-      sg += adv ? 1u : 0u;
-    }
-    const uint32_t sk = cs[sg].start4, src = cs[sg].src;
-    const uint32_t e4 = cs[sg + 1].start4;
-    const uint32_t lim4 = e4 < v1x4 ? e4 : v1x4;
-    const bool is_packed = (sk & SEG_PACKED_BIT) != 0;
-    const bool whole = g0 * 4 + 16 <= lim4 && !(sk & SEG_PARTIAL_BIT);
+    const uint32_t lim4 = e4s[k] < v1x4 ? e4s[k] : v1x4;
+    const bool is_packed = (sk[k] & SEG_PACKED_BIT) != 0;
+    const bool whole = g0 * 4 + 16 <= lim4 && !(sk[k] & SEG_PARTIAL_BIT);
     // a segment holds at most PLAN_SEG_MAX_BYTES of payload: the bit offset inside it fits 32 bits
-    const uint32_t byte0 = h.in_off + src;
-    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk >> 2)) * h.w;
+    const uint32_t byte0 = h.in_off + other[k];
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (g0 - (sk[k] >> 2)) * h.w;
     const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
     const bool fast = whole && is_packed && can_load && w_i <= max_wi;
     const uint32_t kind = g0 >= v1 ? EK_NONE : (is_packed ? (fast ? EK_PACKED : EK_SLOW) : (whole ? EK_RLE : EK_SLOW));
     wi[k] = kind == EK_PACKED ? w_i : 0u;
-    meta[k] = (bitrel & 31u) | (kind << 8) | (sg << 16);
-    other[k] = src;  // the repeated value of an RLE run
+    meta[k] = (bitrel & 31u) | (kind << 8) | (sg[k] << 16);
   }
   // every lane issues every load (units with nothing to read take the page's first dwords, or
   // nothing at all when the page is shorter than one unit load)
