@@ -69,13 +69,14 @@ def build_column(n_pages, elem, seed, device):
     return blob, page_len, ids, dictionary, out
 
 
-def make_descs(blob, page_len, dictionary, out, elem, device):
+def make_descs(blob, page_len, dictionary, out, elem, device, encoding=None, flags=0):
     n_pages = blob.shape[0]
+    encoding = pq.ENC_RLE_DICTIONARY if encoding is None else encoding
     pages = []
     for i in range(n_pages):
         pages.append(dict(data=blob.data_ptr() + i * page_len, out=out.data_ptr() + i * PAGE_VALUES * elem,
                           dict=dictionary.data_ptr(), data_len=page_len, num_values=PAGE_VALUES,
-                          dict_len=DICT_ENTRIES, encoding=pq.ENC_RLE_DICTIONARY, elem_size=elem))
+                          dict_len=DICT_ENTRIES, encoding=encoding, elem_size=elem, flags=flags))
     arr = pq.make_descs(pages)
     d_descs = torch.from_numpy(pq.descs_to_numpy(arr)).to(device)
     d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
@@ -221,6 +222,29 @@ def main():
     pq.check(pq.lib.pqd_phase_ms_mean(phase, C.byref(ncalls)))
     plan_ms, gather_ms, rest_ms = phase[0], phase[1], phase[2]
 
+    # ---- outside the timed region: the other shapes of this workload, for the record
+    extras = {}
+    if rank == 0:
+        def timed(fn, iters=10):
+            fn()
+            torch.cuda.synchronize()
+            a, b = Event(), Event()
+            a.record(stream)
+            for _ in range(iters):
+                fn()
+            b.record(stream)
+            b.sync()
+            return b.ms_since(a) / iters
+        # BINARY column of configs[1]: the reference hands out zero-copy views into the dictionary page
+        # (PlainValuesDictionary.java:96-104), so the device work is the id decode (readValueDictionaryId)
+        c = cols[0]
+        id_descs, id_res = make_descs(c["blob"], c["page_len"], c["dictionary"], c["out"], 4, device,
+                                      encoding=pq.ENC_RLE, flags=pq.F_WIDTH_PREFIX)
+        ms = timed(lambda: pq.decode_pages_dev(id_descs.data_ptr(), id_res.data_ptr(), args.pages, pq.ENC_RLE, 4, stream))
+        ok = bool(torch.equal(c["out"].view(torch.int32), c["ids"]))
+        extras["binary_column_as_dictionary_ids"] = {"ms": round(ms, 4), "values_per_s": round(args.pages * PAGE_VALUES / ms * 1e3, 1),
+                                                     "verified": ok}
+
     n_vals = args.pages * PAGE_VALUES
     decoded_bytes_step = n_vals * (4 + 8)
     encoded_bytes_col = args.pages * cols[0]["page_len"]
@@ -254,6 +278,7 @@ def main():
             "values_per_s": round(2 * n_vals * world / (elapsed / args.steps), 1),
             "algorithmic_GBps": round((2 * encoded_bytes_col + decoded_bytes_step) * world / (elapsed / args.steps) / 1e9, 2),
             "verified_vs_gather": verified,
+            "extras": extras,
             "roofline": {"bound": "hbm", "kernel": "k_dict_pages_sliced<8> (INT64 dictionary pages)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

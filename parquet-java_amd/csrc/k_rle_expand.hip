@@ -163,29 +163,39 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
     }
     if (kind != EK_PACKED) a0 = a1 = a2 = a3 = other[k];
     if (kind == EK_SLOW) {  // run boundaries off multiples of four, truncated runs, the page's last dwords
+      // value by value, but with the eight loads of the unit in flight together
       uint32_t t = meta[k] >> 16;
-      uint32_t v[4] = {0u, 0u, 0u, 0u};
+      uint32_t wj[4], shj[4], vj[4];
+      bool pk[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t g = g0 + j;
-        if (g >= v1) continue;
-        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
+        const uint32_t g = g0 + j < v1 ? g0 + j : v1 - 1;  // values past the end repeat the last one (not stored)
+        while (cs[t + 1].start4 <= g * 4 + 3) ++t;          // stops at the sentinel (start == v1 > g)
         const uint32_t tk = cs[t].start4, src = cs[t].src;
-        if (tk & SEG_PACKED_BIT) {
-          const uint32_t byte0 = h.in_off + src;
-          const uint64_t bitrel = (uint64_t)(byte0 & 3u) * 8 + (uint64_t)(g - (tk >> 2)) * h.w;
-          const uint32_t wj = (byte0 >> 2) + (uint32_t)(bitrel >> 5);
-          const uint32_t sh = (uint32_t)bitrel & 31u;
-          const uint32_t x0 = ex_guarded_word(h, wj), x1 = ex_guarded_word(h, wj + 1);
-          v[j] = funnel_shr(x0, x1, sh) & mask;
-        } else {
-          v[j] = src;
-        }
+        const uint32_t byte0 = h.in_off + src;
+        const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
+        pk[j] = (tk & SEG_PACKED_BIT) != 0;
+        wj[j] = pk[j] ? (byte0 >> 2) + (bitrel >> 5) : 0u;
+        shj[j] = bitrel & 31u;
+        vj[j] = src;
       }
-      a0 = v[0];
-      a1 = v[1];
-      a2 = v[2];
-      a3 = v[3];
+      uint32_t x0[4], x1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // clamped addresses: never past the page
+        x0[j] = h.words[wj[j] < h.last_word ? wj[j] : h.last_word];
+        x1[j] = h.words[wj[j] + 1 < h.last_word ? wj[j] + 1 : h.last_word];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // bytes at or past the end of the stream read as zero
+        const uint32_t i0 = wj[j], i1 = wj[j] + 1;
+        const uint32_t y0 = i0 < h.full_words ? x0[j] : (i0 == h.full_words ? x0[j] & h.tail_mask : 0u);
+        const uint32_t y1 = i1 < h.full_words ? x1[j] : (i1 == h.full_words ? x1[j] & h.tail_mask : 0u);
+        vj[j] = pk[j] ? funnel_shr(y0, y1, shj[j]) & mask : vj[j];
+      }
+      a0 = vj[0];
+      a1 = vj[1];
+      a2 = vj[2];
+      a3 = vj[3];
     }
     if (g0 + 4 <= v1) {
       const u32x4_a4 r4 = {a0, a1, a2, a3};
