@@ -343,6 +343,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   uint64_t tag_dict = 0;
   uint32_t tag_s0 = ~0u, tag_s1 = ~0u;
   uint32_t last_buf = 1;   // buffer of the latest pass
+  uint32_t res_win = ~0u;  // window mode: which window (0 / 1) the two buffers hold; ~0: none
   bool descending = false;  // slice order of the current page
 
   uint32_t page = blockIdx.x;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     if (n_out && dict_addr != tag_dict) {  // another dictionary: nothing resident is of use
       tag_dict = dict_addr;
       tag_s0 = tag_s1 = ~0u;
+      res_win = ~0u;
     }
     PROF(0)
 
@@ -393,24 +395,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     extract<UNITS>(cs, n_out, h, tid, raw, id);
     PROF(1)
 
-    // ---- 2. prefetch: the plan of the page after the next, the packed dwords of the next page.
-    // The loads are issued unconditionally (from a harmless address when there is nothing to
-    // fetch) so that exactly UNITS of them are this wave's most recent memory operations when it
-    // reaches the first barrier of the sweep.
-    if (next_page + stride < n_pages && next_page + stride >= next_page)
-      fetch_plan_async(plans, pool, next_page + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES,
-                       lds0 + DS_OFF_PLANS + nnb * DS_PLAN_BYTES, wave, lane);
-    {
-      // without a next page this reads the stale record of an earlier page (or nothing fetched
-      // yet): only its load base is used, and read_head makes that harmless for unusable records
-      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES), plans);
-      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
-      locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), ok ? nh.n_out : 0u, nh, tid, wave,
-                          raw PROF_FN_ARG);
-    }
-    PROF(8)
-
-    // ---- 3. ids beyond the dictionary: note the first one, and look up entry 0 instead.
+    // ---- 2. ids beyond the dictionary: note the first one, and look up entry 0 instead.
     // A page whose id width cannot express such an id skips the check.
     if (h.w >= 32 || (1u << h.w) > dict_len) {
       uint32_t bad = ~0u;
@@ -428,8 +413,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     }
     PROF(2)
 
-    // ---- 4. gather: every pass looks up the ids that fall into the resident slice.
-    // Byte offsets into the dictionary, so that a pass costs a subtraction and a compare per id.
+    // ---- 3. gather.  Byte offsets into the dictionary, so that a pass costs a subtraction and a
+    // compare per id; a pass looks up the ids that fall into the part of the dictionary in LDS.
 #pragma unroll
     for (int r = 0; r < R; ++r) id[r] *= ELEM;
     uint32_t vlo[R], vhi[ELEM == 8 ? R : 1];
@@ -438,51 +423,13 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
       vlo[r] = 0;
       vhi[ELEM == 8 ? r : 0] = 0;
     }
-    // Pass order alternates between pages (0,1,..,P-1 then P-1,..,1,0): the two slices a page ends
-    // with are the two the next page starts with, so a page moves only P - 2 slices into LDS.
-    bool prefetch_only = true;  // this wave's memory operations since the last barrier: the prefetch loads alone
-    for (uint32_t i = 0; i < P; ++i) {
-      const uint32_t s = descending ? P - 1 - i : i;
-      uint32_t curb = tag_s0 == s ? 0u : (tag_s1 == s ? 1u : last_buf ^ 1u);
-      // the slice this pass needs, if it is not resident
-      if ((curb ? tag_s1 : tag_s0) != s) {
-        wg_barrier();  // nobody still reads this buffer
-        const uint32_t n_here = dict_len - s * S < S ? dict_len - s * S : S;
-        load_slice(dict_bytes + (size_t)s * DS_SLICE_BYTES, n_here * ELEM, lds0 + curb * DS_SLICE_BYTES, wave, lane);
-        if (curb)
-          tag_s1 = s;
-        else
-          tag_s0 = s;
-        prefetch_only = false;
-      }
-      last_buf = curb;
-      PROF(5)
-      // this pass's slice has landed; everybody is done with the other buffer
-      if (prefetch_only)
-        wg_barrier_keep<UNITS>();  // the prefetch loads stay in flight
-      else
-        wg_barrier();
-      prefetch_only = false;
-      PROF(3)
-      // bring in the slice of the next pass
-      if (i + 1 < P) {
-        const uint32_t nx = descending ? s - 1 : s + 1;
-        if (tag_s0 != nx && tag_s1 != nx) {
-          const uint32_t n_here = dict_len - nx * S < S ? dict_len - nx * S : S;
-          load_slice(dict_bytes + (size_t)nx * DS_SLICE_BYTES, n_here * ELEM, lds0 + (curb ^ 1u) * DS_SLICE_BYTES, wave, lane);
-          if (curb)
-            tag_s0 = nx;
-          else
-            tag_s1 = nx;
-        }
-      }
-      PROF(9)
-      const uint32_t s0b = s * DS_SLICE_BYTES;
-      const PQD_LDS uint8_t* buf = (const PQD_LDS uint8_t*)(lds + curb * DS_SLICE_BYTES);
+    // ids whose dictionary byte offset lies in [base, base + limit) are looked up at lds[offset - base + at]
+    auto lookups = [&](uint32_t base, uint32_t limit, uint32_t at) {
+      const PQD_LDS uint8_t* buf = (const PQD_LDS uint8_t*)lds + at;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const uint32_t a = id[r] - s0b;
-        if (a < DS_SLICE_BYTES) {
+        const uint32_t a = id[r] - base;
+        if (a < limit) {
           if (ELEM == 4) {
             vlo[r] = *(const PQD_LDS uint32_t*)(buf + a);
           } else {
@@ -492,7 +439,113 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
           }
         }
       }
+    };
+    // Dictionaries of up to four slices are handled in WINDOWS of two slices (the two LDS buffers
+    // side by side): half as many passes over the ids.  With two windows, a page starts with the
+    // window the page before ended with, so a page switches windows once; the switch (128 KiB of
+    // LDS-DMA) runs behind the prefetch work for the next page.
+    // (8-byte values keep to single slices: the extra code costs them registers they do not have)
+    const bool wide = ELEM == 4 && P <= 4;
+    const bool two_windows = P > 2 && wide;
+    const uint32_t dict_bytes_total = dict_len * ELEM;
+    auto load_window = [&](uint32_t win) {  // slices 2*win and 2*win + 1 into buffers 0 and 1
+#pragma unroll
+      for (uint32_t half = 0; half < 2; ++half) {
+        const uint32_t sl = 2 * win + half;
+        if (sl < P) {
+          const uint32_t n_here = dict_len - sl * S < S ? dict_len - sl * S : S;
+          load_slice(dict_bytes + (size_t)sl * DS_SLICE_BYTES, n_here * ELEM, lds0 + half * DS_SLICE_BYTES, wave, lane);
+        }
+      }
+    };
+    if (wide && P > 0 && res_win > 1u) {  // nothing of this dictionary is resident (first page, other dictionary)
+      wg_barrier();  // nobody still reads the buffers
+      load_window(0);
+      res_win = 0;
+      tag_s0 = tag_s1 = ~0u;  // the per-slice bookkeeping of the narrow mode no longer holds
+      wg_barrier();
+    }
+    if (two_windows) {
+      const uint32_t wbase = res_win * 2 * DS_SLICE_BYTES;
+      lookups(wbase, 2 * DS_SLICE_BYTES, 0u);
       PROF(4)
+      wg_barrier_lds();  // everybody is done with the resident window
+      res_win ^= 1u;
+      load_window(res_win);
+      PROF(9)
+    }
+
+    // ---- 4. prefetch: the plan of the page after the next, the packed dwords of the next page.
+    // The loads are issued unconditionally (from a harmless address when there is nothing to
+    // fetch) so that exactly UNITS of them are this wave's most recent memory operations when it
+    // reaches the next barrier.
+    if (next_page + stride < n_pages && next_page + stride >= next_page)
+      fetch_plan_async(plans, pool, next_page + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES,
+                       lds0 + DS_OFF_PLANS + nnb * DS_PLAN_BYTES, wave, lane);
+    {
+      // without a next page this reads the stale record of an earlier page (or nothing fetched
+      // yet): only its load base is used, and read_head makes that harmless for unusable records
+      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES), plans);
+      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
+      locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), ok ? nh.n_out : 0u, nh, tid, wave,
+                          raw PROF_FN_ARG);
+    }
+    PROF(8)
+
+    if (two_windows) {
+      wg_barrier_keep<UNITS>();  // the other window has landed; the prefetch loads stay in flight
+      PROF(3)
+      lookups(res_win * 2 * DS_SLICE_BYTES, 2 * DS_SLICE_BYTES, 0u);
+      PROF(4)
+    } else if (wide) {
+      if (P > 0) lookups(0u, dict_bytes_total, 0u);  // the whole dictionary is in LDS
+      PROF(4)
+    } else {
+      // More than four slices: one slice per pass, double-buffered.  Pass order alternates between
+      // pages (0,1,..,P-1 then P-1,..,1,0): the two slices a page ends with are the two the next
+      // page starts with, so a page moves only P - 2 slices into LDS.
+      res_win = ~0u;
+      bool prefetch_only = true;  // this wave's memory operations since the last barrier: the prefetch loads alone
+      for (uint32_t i = 0; i < P; ++i) {
+        const uint32_t s = descending ? P - 1 - i : i;
+        uint32_t curb = tag_s0 == s ? 0u : (tag_s1 == s ? 1u : last_buf ^ 1u);
+        // the slice this pass needs, if it is not resident
+        if ((curb ? tag_s1 : tag_s0) != s) {
+          wg_barrier();  // nobody still reads this buffer
+          const uint32_t n_here = dict_len - s * S < S ? dict_len - s * S : S;
+          load_slice(dict_bytes + (size_t)s * DS_SLICE_BYTES, n_here * ELEM, lds0 + curb * DS_SLICE_BYTES, wave, lane);
+          if (curb)
+            tag_s1 = s;
+          else
+            tag_s0 = s;
+          prefetch_only = false;
+        }
+        last_buf = curb;
+        PROF(5)
+        // this pass's slice has landed; everybody is done with the other buffer
+        if (prefetch_only)
+          wg_barrier_keep<UNITS>();  // the prefetch loads stay in flight
+        else
+          wg_barrier();
+        prefetch_only = false;
+        PROF(3)
+        // bring in the slice of the next pass
+        if (i + 1 < P) {
+          const uint32_t nx = descending ? s - 1 : s + 1;
+          if (tag_s0 != nx && tag_s1 != nx) {
+            const uint32_t n_here = dict_len - nx * S < S ? dict_len - nx * S : S;
+            load_slice(dict_bytes + (size_t)nx * DS_SLICE_BYTES, n_here * ELEM, lds0 + (curb ^ 1u) * DS_SLICE_BYTES, wave, lane);
+            if (curb)
+              tag_s0 = nx;
+            else
+              tag_s1 = nx;
+          }
+        }
+        PROF(9)
+        lookups(s * DS_SLICE_BYTES, DS_SLICE_BYTES, curb * DS_SLICE_BYTES);
+        PROF(4)
+      }
+      descending = !descending;
     }
 
     // ---- 5. store, 16 bytes per lane per instruction
@@ -527,7 +580,6 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
         }
       }
     }
-    if (P > 1) descending = !descending;
     PROF(6)
 
     // ---- 6. page end.  All atomicMin on this page's oob slot are in after the barrier; the slot is
@@ -535,6 +587,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     // plan DMA issued above has landed: it takes the full one.
     if (P == 0)
       wg_barrier();
+    else if (wide && !two_windows)
+      wg_barrier_keep<UNITS>();  // the only barrier of such a page: waits for everything but this page's last stores
     else
       wg_barrier_lds();
     if (!skip && tid == 0) {
