@@ -36,20 +36,26 @@ struct PlanState {
   uint32_t next_stride; // length of the last run walked: stride of the next round ...
   uint32_t prev_stride; // ... if the run before it had the same length (else the round is one contiguous KiB)
   uint32_t chunk_slot;  // pool chunk obtained for the flush in progress
+  uint32_t list_n, list_after, list_stop;  // result of the chain walk of plan_window
 };
 
 // One lane.  Emits segments into `stage` until the stage is full, the walk leaves the header
 // window, or the page is finished.
 __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uint32_t w, uint32_t end,
-                          uint32_t n_values, uint32_t seg_groups_cap, uint32_t seg_limit) {
+                          uint32_t n_values, uint32_t seg_groups_cap, uint32_t seg_limit, uint32_t max_runs) {
   uint32_t pos = st.pos, vals = st.vals, pending = st.pending, ns = st.nstage;
   const uint32_t pos0 = st.round_pos0, stride = st.round_stride;
   uint32_t blk = 0, blk_pos = pos0, next_stride = st.next_stride, prev_stride = st.prev_stride;  // block that may hold the next header
   int32_t status = PQD_OK;
   bool need_round = false;
+  uint32_t runs = 0;
   while (ns < seg_limit && vals < n_values) {
     const uint32_t rem = n_values - vals;
     if (pending == 0) {
+      if (runs++ >= max_runs) {  // the caller wants the window parsed anew from here
+        need_round = true;
+        break;
+      }
       if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
         status = PQD_PAST_END;
         break;
@@ -184,6 +190,157 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
   st.prev_stride = prev_stride;
 }
 
+// A candidate run header at some byte of the header window, decoded from the eight bytes `x` that
+// start there.  `len` = bytes to the next header, `nvals` = values the run yields, `src` = the
+// repeated value (RLE) or the offset of the payload from the header's first byte (bit-packed).
+struct Cand {
+  uint32_t len, nvals, src;
+  bool packed, complex;  // complex: not for the parallel path (the serial walk knows all the rules)
+};
+
+__device__ __forceinline__ Cand parse_cand(uint64_t x, uint32_t w, uint32_t vb) {
+  Cand c;
+  const uint32_t lo = (uint32_t)x;
+  const uint32_t c0 = (lo >> 7) & 1u, c1 = (lo >> 15) & 1u, c2 = (lo >> 23) & 1u, c3 = lo >> 31;
+  const uint32_t nb = 1 + c0 + (c0 & c1) + (c0 & c1 & c2);  // bytes of the varint header, if at most four
+  uint32_t h = (lo & 0x7Fu) | (((lo >> 8) & 0x7Fu) << 7) | (((lo >> 16) & 0x7Fu) << 14) | (((lo >> 24) & 0x7Fu) << 21);
+  h &= (1u << (7 * nb)) - 1u;
+  const uint32_t cnt = h >> 1;
+  c.packed = (h & 1u) != 0;
+  c.complex = (c0 & c1 & c2 & c3) != 0 || cnt == 0;  // a longer header; a zero-count RLE run (repeats for ever) / empty packed run
+  if (c.packed) {
+    const uint64_t bytes = (uint64_t)cnt * w;
+    c.complex = c.complex || bytes > (uint64_t)PLAN_SEG_MAX_BYTES || cnt > 0x0FFFFFFFu;
+    c.len = nb + (uint32_t)bytes;
+    c.nvals = cnt * 8;
+    c.src = nb;
+    if (w == 0) {  // no payload: eight zeros per group
+      c.packed = false;
+      c.src = 0;
+    }
+  } else {
+    c.len = nb + vb;
+    c.nvals = cnt;
+    const uint64_t v = x >> (8 * nb);
+    c.src = vb == 0 ? 0u : (uint32_t)(v & (vb >= 4 ? 0xFFFFFFFFull : ((1ull << (8 * vb)) - 1ull)));  // not masked to w bits
+  }
+  return c;
+}
+
+constexpr int PLAN_WINDOW = 16 * PLAN_SLOTS;  // bytes of a contiguous round
+constexpr uint32_t NXT_COMPLEX = 0xFFFFu, NXT_STOP = 0xFFFEu;
+
+// Parallel planning of a contiguous header window (all lanes).  Every lane decodes the sixteen
+// candidate headers that start at its own bytes and writes where each would lead (`nxt`); lane 0
+// follows that chain from the stream position, which is one LDS read per run; then the runs found
+// are turned into segments 64 at a time, their output positions by a wave prefix sum.  Runs the
+// parallel rules do not cover (see parse_cand; also anything that touches the end of the stream)
+// stop the chain: the serial walk takes that one run and the next round starts behind it.
+__device__ __forceinline__ void plan_window(PlanState& st, const u32x4* win4, uint16_t* nxt, uint16_t* list, RleSeg* stage,
+                                            uint32_t end, uint32_t w, uint32_t n_values, uint32_t seg_limit, uint32_t tid) {
+  const uint32_t pos0 = st.round_pos0;
+  const uint32_t entry = st.pos - pos0;
+  const uint32_t vb = (w + 7) >> 3;
+  const bool to_end = (uint64_t)pos0 + PLAN_WINDOW >= end;  // the window holds the rest of the stream
+  // ---- A. candidates
+  {
+    const u32x4 a = win4[tid], b = win4[tid + 1];  // win4[PLAN_SLOTS] is zero
+    const uint32_t d[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+    uint16_t out[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t p = 16 * tid + j;
+      const uint32_t sh = (j & 3) * 8;
+      const uint32_t x0 = funnel_shr(d[j >> 2], d[(j >> 2) + 1], sh), x1 = funnel_shr(d[(j >> 2) + 1], d[(j >> 2) + 2 < 6 ? (j >> 2) + 2 : 5], sh);
+      const Cand c = parse_cand(((uint64_t)x1 << 32) | x0, w, vb);
+      uint32_t v = p + c.len;  // < 1024 + 4 + PLAN_SEG_MAX_BYTES
+      if (c.complex || (uint64_t)pos0 + p + c.len > end) v = NXT_COMPLEX;
+      if (p + PLAN_NEED > (uint32_t)PLAN_WINDOW && !to_end) v = NXT_STOP;  // its bytes may lie outside the window
+      if ((uint64_t)pos0 + p >= end) v = NXT_COMPLEX;                      // a header at the end of the stream: the serial walk reports it
+      out[j] = (uint16_t)v;
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(nxt + 16 * tid);
+    dst[0] = u32x4{(uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16),
+                   (uint32_t)out[4] | ((uint32_t)out[5] << 16), (uint32_t)out[6] | ((uint32_t)out[7] << 16)};
+    dst[1] = u32x4{(uint32_t)out[8] | ((uint32_t)out[9] << 16), (uint32_t)out[10] | ((uint32_t)out[11] << 16),
+                   (uint32_t)out[12] | ((uint32_t)out[13] << 16), (uint32_t)out[14] | ((uint32_t)out[15] << 16)};
+  }
+  __syncthreads();
+  // ---- B. the chain from the stream position
+  if (tid == 0) {
+    uint32_t n = 0, p = entry, stop = NXT_STOP;
+    while (p < (uint32_t)PLAN_WINDOW && n < (uint32_t)PLAN_WINDOW) {
+      const uint32_t q = nxt[p];
+      if (q >= NXT_STOP) {
+        stop = q;
+        break;
+      }
+      list[n++] = (uint16_t)p;
+      p = q;
+    }
+    st.list_n = n;
+    st.list_after = p;     // window offset behind the last run listed
+    st.list_stop = stop;   // NXT_COMPLEX: the run at list_after is for the serial walk
+  }
+  __syncthreads();
+  // ---- C. segments, 64 runs at a time
+  const uint32_t n = st.list_n;
+  const uint32_t* wb = reinterpret_cast<const uint32_t*>(win4);
+  uint32_t vals = st.vals, ns = st.nstage, taken = 0;
+  bool finished = false, full = false;
+  for (uint32_t base = 0; base < n && !finished && !full; base += PLAN_THREADS) {
+    const bool have = base + tid < n;
+    const uint32_t p = have ? list[base + tid] : 0u;
+    const uint32_t i0 = p >> 2, sh = (p & 3u) * 8;
+    const uint32_t x0 = funnel_shr(wb[i0], wb[i0 + 1], sh), x1 = funnel_shr(wb[i0 + 1], wb[i0 + 2], sh);
+    const Cand c = parse_cand(((uint64_t)x1 << 32) | x0, w, vb);
+    const uint32_t cap = n_values - vals;  // > 0 here
+    const uint32_t mine = have ? (c.nvals < cap ? c.nvals : cap) : 0u;
+    // inclusive prefix sum over the wave, saturating at cap (all operands <= 2^30)
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(inc, off, 64);
+      if (tid >= (uint32_t)off) {
+        inc += up;
+        inc = inc < cap ? inc : cap;
+      }
+    }
+    const uint32_t prev_inc = __shfl_up(inc, 1, 64);
+    const uint32_t before = tid == 0 ? 0u : prev_inc;  // values of the runs before this one, saturated at cap
+    const bool live = have && before < cap && ns + tid < seg_limit;  // starts inside the page and fits the stage
+    const uint64_t lm = __builtin_amdgcn_ballot_w64(live);
+    const uint32_t m = lm == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~lm);  // leading live runs
+    if (tid < m) {
+      stage[ns + tid].start4 = ((vals + before) << 2) | (c.packed ? SEG_PACKED_BIT : 0u);
+      stage[ns + tid].src = c.packed ? pos0 + p + c.src : c.src;
+    }
+    const uint32_t have_n = n - base < (uint32_t)PLAN_THREADS ? n - base : (uint32_t)PLAN_THREADS;
+    const uint32_t total = m ? __shfl(inc, (int)m - 1, 64) : 0u;  // values of the runs taken (saturated)
+    vals += total;
+    ns += m;
+    taken += m;
+    if (vals >= n_values) finished = true;
+    if (m < have_n) full = !finished;  // stopped for lack of stage room
+  }
+  if (tid == 0) {
+    st.vals = vals;
+    st.nstage = ns;
+    const uint32_t after = taken < n ? (uint32_t)list[taken] : st.list_after;
+    if (taken) {
+      st.pos = pos0 + after;
+      // the lengths of the last two runs taken: what decides between a strided and a contiguous round
+      const uint32_t last = after - list[taken - 1];
+      st.prev_stride = taken >= 2 ? (uint32_t)list[taken - 1] - list[taken - 2] : st.next_stride;
+      st.next_stride = last;
+    }
+    if (finished) st.done = 1;
+    // a complex run right behind the ones taken goes to the serial walk with this window; otherwise fetch anew
+    st.need_round = (!finished && !full && taken == n && st.list_stop == NXT_COMPLEX) ? 0u : 1u;
+  }
+  __syncthreads();
+}
+
 // One fetch round (all lanes): lane l loads the 16 bytes at pos + l*stride into the header window
 // (bytes past the stream end read as zero).  When the stride is a run length (the last run walked
 // was a bit-packed run of `stride` bytes), the lanes then try the regular case in parallel: every
@@ -263,7 +420,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
                                                            uint32_t n_pages, int want_dict, int elem) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
+  __shared__ u32x4 nxt4[PLAN_WINDOW / 8], list4[PLAN_WINDOW / 8];
   __shared__ PlanState st;
+  uint16_t* nxt = reinterpret_cast<uint16_t*>(nxt4);
+  uint16_t* list = reinterpret_cast<uint16_t*>(list4);
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -358,8 +518,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
   uint32_t nseg = 0;
   bool fallback = false;
   for (;;) {
-    if (st.need_round) plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
-    if (tid == 0 && !st.need_round && !st.done) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_MAX + 1);
+    bool fresh = false;
+    if (st.need_round) {
+      plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
+      fresh = true;
+    }
+    // a fresh contiguous window is planned by all lanes; the serial walk takes only what that leaves
+    const bool windowed = fresh && st.round_stride == 16 && st.pending == 0 && !st.done && st.nstage <= (uint32_t)SEG_MAX;
+    if (windowed) plan_window(st, win4, nxt, list, stage, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
+    if (tid == 0 && !st.need_round && !st.done)
+      plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_MAX + 1, windowed ? 1u : ~0u);
     __syncthreads();
     const uint32_t ns = st.nstage;
     const bool done = st.done != 0;
@@ -439,7 +607,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
+  __shared__ u32x4 nxt4[PLAN_WINDOW / 8], list4[PLAN_WINDOW / 8];
   __shared__ PlanState st;
+  uint16_t* nxt = reinterpret_cast<uint16_t*>(nxt4);
+  uint16_t* list = reinterpret_cast<uint16_t*>(list4);
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -529,8 +700,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   uint32_t v0 = 0;  // start of the chunk being collected
   bool fallback = false;
   for (;;) {
-    if (st.need_round) plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
-    if (tid == 0 && !st.need_round && !st.done) plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_GEN_MAX);
+    bool fresh = false;
+    if (st.need_round) {
+      plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
+      fresh = true;
+    }
+    // a fresh contiguous window is planned by all lanes; the serial walk takes only what that leaves
+    const bool windowed = fresh && st.round_stride == 16 && st.pending == 0 && !st.done && st.nstage < (uint32_t)SEG_GEN_MAX;
+    if (windowed) plan_window(st, win4, nxt, list, stage, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
+    if (tid == 0 && !st.need_round && !st.done)
+      plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_GEN_MAX, windowed ? 1u : ~0u);
     __syncthreads();
     const bool done = st.done != 0;
     const uint32_t vals = st.vals;
