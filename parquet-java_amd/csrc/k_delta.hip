@@ -76,6 +76,24 @@ __device__ __forceinline__ int64_t zigzag64(uint64_t raw) {  // BytesUtils.java:
   return (int64_t)((raw >> 1) ^ (~(raw & 1ull) + 1ull));
 }
 
+// Reads the 16 bytes at window offset `off`, where a block header starts: the length of the
+// min-delta varint from its continuation bits (`nbv`, 1..8) and the sum of the first `take` width
+// bytes behind it (`wsum`).  False if the varint is longer than 8 bytes or a width exceeds 64.
+__device__ __forceinline__ bool quick_block(lds_words_t win, uint32_t off, uint32_t mn, uint32_t take, uint32_t& nbv,
+                                            uint32_t& wsum) {
+  const uint32_t i0 = off >> 2, sh = (off & 3u) * 8u;
+  const uint32_t a0 = win[i0], a1 = win[i0 + 1], a2 = win[i0 + 2], a3 = win[i0 + 3], a4 = win[i0 + 4];
+  const uint32_t b0 = funnel_shr(a0, a1, sh), b1 = funnel_shr(a1, a2, sh), b2 = funnel_shr(a2, a3, sh), b3 = funnel_shr(a3, a4, sh);
+  const uint64_t lo = ((uint64_t)b1 << 32) | b0, hi = ((uint64_t)b3 << 32) | b2;
+  const uint64_t stop = ~lo & 0x8080808080808080ull;  // bytes without the continuation bit
+  nbv = stop ? ((uint32_t)__builtin_ctzll(stop) >> 3) + 1 : 8u;
+  const uint64_t wbytes = nbv == 8 ? hi : ((lo >> (8 * nbv)) | (hi << (64 - 8 * nbv)));
+  const uint64_t used = take >= 8 ? wbytes : (wbytes & ((1ull << (8 * take)) - 1ull));
+  wsum = __builtin_amdgcn_sad_u8((uint32_t)used, 0u, __builtin_amdgcn_sad_u8((uint32_t)(used >> 32), 0u, 0u));
+  (void)mn;
+  return stop != 0 && !(used & 0x8080808080808080ull) && !((used + 0x3F3F3F3F3F3F3F3Full) & 0x8080808080808080ull);
+}
+
 template <int ELEM>
 __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_desc* __restrict__ descs,
                                                                pqd_page_result* __restrict__ results,
@@ -88,6 +106,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   __shared__ uint8_t cur_widths[MAX_MINI_PER_BLOCK];
   __shared__ acc_t wave_sum[DELTA_THREADS / 64];
   __shared__ uint32_t blk_off[MAX_FAST_BLOCKS];  // window offset of the block headers found by the quick walk
+  __shared__ uint32_t spec_first_no[DELTA_THREADS / 64];
   __shared__ DeltaState st;
   lds_words_t win = (lds_words_t)(const PQD_LDS u32x4*)win4;
 
@@ -168,6 +187,37 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       __syncthreads();
     }
     // ---- 2. block-header walk (loadNewBlockToBuffer, :121-143; readBitWidthsForMiniBlocks, :164-172)
+    // 2a. All lanes at once, for the usual case of blocks of one length L (steady delta widths):
+    // lane t looks at offset t * L behind the first block and checks that a full block of that same
+    // length starts there.  The blocks up to the first lane that says no are taken as found.
+    uint32_t spec_m = 0, spec_L = 0;
+    {
+      const int32_t base = first_window ? st.window_base : wbase;
+      const uint32_t wend = (uint32_t)(base + DWINDOW_BYTES);
+      const uint32_t p = st.pos, mn = st.mini_n, scanned = st.deltas_done;
+      const bool can = st.minis_left == 0 && mn <= 8 && mn > 0;
+      bool ok = false;
+      if (can && p + 16 <= end && p + 16 <= wend) {
+        uint32_t nbv0, wsum0;
+        const bool ok0 = quick_block(win, (uint32_t)(p - base), mn, mn, nbv0, wsum0);
+        spec_L = nbv0 + mn + (mini_size >> 3) * wsum0;
+        const uint64_t pt = (uint64_t)p + (uint64_t)tid * spec_L;
+        if (ok0 && pt + 16 <= end && pt + 16 <= wend && pt + spec_L <= end && pt + spec_L <= wend &&
+            (uint64_t)scanned + (uint64_t)(tid + 1) * st.block_size <= n_deltas && (tid + 1) * mn <= (uint32_t)MAX_MINIS) {
+          uint32_t nbv, wsum;
+          const uint32_t off = (uint32_t)(pt - base);
+          ok = quick_block(win, off, mn, mn, nbv, wsum) && nbv + mn + (mini_size >> 3) * wsum == spec_L;
+          if (ok) blk_off[tid] = off;  // entries past the first refusal are ignored
+        }
+      }
+      const uint64_t no = ~__builtin_amdgcn_ballot_w64(ok);
+      if ((tid & 63u) == 0) spec_first_no[tid >> 6] = (tid & ~63u) + (no ? (uint32_t)__builtin_ctzll(no) : 64u);
+      __syncthreads();
+      spec_m = DELTA_THREADS;
+#pragma unroll
+      for (int k = DELTA_THREADS / 64 - 1; k >= 0; --k)
+        if (spec_first_no[k] < (uint32_t)(k + 1) * 64u) spec_m = spec_first_no[k];
+    }
     if (tid == 0) {
       const int32_t base = first_window ? st.window_base : wbase;
       st.window_base = base;
@@ -231,26 +281,31 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       // above 64, the end of the stream or of the window in sight) ends it, and the careful walk
       // below carries on from that block and reports what is wrong with it.
       uint32_t nblk = 0, last_take = st.mini_n;
+      bool window_full = false;  // the walk stopped in front of a whole block that does not fit the window
       if (left == 0 && st.mini_n <= 8 && status == PQD_OK) {
         const uint32_t mn = st.mini_n;
+        // the blocks found by all lanes above
+        nblk = spec_m;
+        nm += spec_m * mn;
+        p += spec_m * spec_L;
+        scanned += spec_m * st.block_size;
         while (nm + mn <= MAX_MINIS && nblk < (uint32_t)MAX_FAST_BLOCKS && scanned < n_deltas) {
-          if (p + 16 > end || p + 16 > wend) break;
-          const uint32_t off = (uint32_t)(p - base), i0 = off >> 2, sh = (off & 3u) * 8u;
-          const uint32_t a0 = win[i0], a1 = win[i0 + 1], a2 = win[i0 + 2], a3 = win[i0 + 3], a4 = win[i0 + 4];
-          const uint32_t b0 = funnel_shr(a0, a1, sh), b1 = funnel_shr(a1, a2, sh), b2 = funnel_shr(a2, a3, sh),
-                         b3 = funnel_shr(a3, a4, sh);
-          const uint64_t lo = ((uint64_t)b1 << 32) | b0, hi = ((uint64_t)b3 << 32) | b2;
-          const uint64_t stop = ~lo & 0x8080808080808080ull;  // bytes without the continuation bit
-          if (!stop) break;
-          const uint32_t nbv = ((uint32_t)__builtin_ctzll(stop) >> 3) + 1;  // 1..8 bytes of min delta
-          const uint64_t wbytes = nbv == 8 ? hi : ((lo >> (8 * nbv)) | (hi << (64 - 8 * nbv)));
-          const uint32_t need = (n_deltas - scanned + mini_size - 1) / mini_size;
-          const uint32_t take = need < mn ? need : mn;
-          const uint64_t used = take == 8 ? wbytes : (wbytes & ((1ull << (8 * take)) - 1ull));
-          if ((used & 0x8080808080808080ull) || ((used + 0x3F3F3F3F3F3F3F3Full) & 0x8080808080808080ull)) break;  // a width > 64
-          const uint32_t wsum = __builtin_amdgcn_sad_u8((uint32_t)used, 0u, __builtin_amdgcn_sad_u8((uint32_t)(used >> 32), 0u, 0u));
+          if (p + 16 > end) break;
+          if (p + 16 > wend) {
+            window_full = nm > 0;
+            break;
+          }
+          const uint32_t off = (uint32_t)(p - base);
+          const uint32_t left_minis = (n_deltas - scanned + mini_size - 1) / mini_size;
+          const uint32_t take = left_minis < mn ? left_minis : mn;
+          uint32_t nbv, wsum;
+          if (!quick_block(win, off, mn, take, nbv, wsum)) break;
           const uint32_t pay = p + nbv + mn, bytes = mini_bytes_unit * wsum;
-          if (end - pay < bytes || pay + bytes > wend) break;
+          if (end - pay < bytes) break;
+          if (pay + bytes > wend) {
+            window_full = nm > 0;
+            break;
+          }
           blk_off[nblk] = off;
           ++nblk;
           last_take = take;
@@ -262,7 +317,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       st.fast_blocks = nblk;
       st.fast_take = last_take;
       st.fast_base = fast_base;
-      careful_walk(false);
+      if (!window_full) careful_walk(false);  // (a window that ends between blocks lets the next one start with all lanes)
       st.pos = p;
       st.window_minis = nm;
       st.minis_left = left;
