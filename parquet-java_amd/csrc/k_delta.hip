@@ -174,6 +174,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   acc_t carry = (acc_t)st.first;  // value at output index deltas_done
   acc_t* out = reinterpret_cast<acc_t*>(d.out);
   bool first_window = true;
+  constexpr int NEXT_PIECES = (DWINDOW_PIECES + DELTA_THREADS - 1) / DELTA_THREADS;
+  u32x4 next_win[NEXT_PIECES];  // the next window on its way from memory while this one is unpacked
 
   while (st.done == 0) {
     // ---- 1. stage (the header window is reused for the first pass)
@@ -182,8 +184,13 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
     const uint8_t* gbase = reinterpret_cast<const uint8_t*>((uintptr_t)gptr & ~(uintptr_t)15);
     const int32_t wbase = (int32_t)cur - (int32_t)(gptr - gbase);
     if (!first_window) {
+      // the window was requested (into registers) before the previous one was unpacked
       __syncthreads();
-      stage_window<DELTA_THREADS>(win4, gbase, gend, DWINDOW_PIECES);
+#pragma unroll
+      for (int j = 0; j < NEXT_PIECES; ++j) {
+        const int i = (int)tid + j * DELTA_THREADS;
+        if (i < DWINDOW_PIECES) win4[i] = keep_leading_bytes(next_win[j], (long)(gend - (gbase + (size_t)i * 16)));
+      }
       __syncthreads();
     }
     // ---- 2. block-header walk (loadNewBlockToBuffer, :121-143; readBitWidthsForMiniBlocks, :164-172)
@@ -332,6 +339,17 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
     }
     __syncthreads();
     first_window = false;
+    if (st.done == 0 && st.status == PQD_OK) {  // request the next window now; it lands behind the unpacking
+      const uint8_t* nptr = d.data + st.pos;
+      const uint8_t* nbase = reinterpret_cast<const uint8_t*>((uintptr_t)nptr & ~(uintptr_t)15);
+#pragma unroll
+      for (int j = 0; j < NEXT_PIECES; ++j) {
+        const int i = (int)tid + j * DELTA_THREADS;
+        const uint8_t* q = nbase + (size_t)i * 16;
+        next_win[j] = u32x4{0u, 0u, 0u, 0u};
+        if (i < DWINDOW_PIECES && q < gend) next_win[j] = *reinterpret_cast<const u32x4*>(q);
+      }
+    }
     // one lane per block found by the quick walk: min delta, widths -> miniblock table entries
     {
       const uint32_t nblk = st.fast_blocks, mn = st.mini_n;
