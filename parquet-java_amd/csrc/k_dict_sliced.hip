@@ -7,8 +7,9 @@
 // line per value and runs at about 0.3 values/clk/CU; an LDS gather runs an order of magnitude
 // faster, so instead of sending each id to the dictionary the dictionary is brought to the ids:
 //
-//   - one 1024-thread workgroup per CU walks over pages; the run plan of each page comes from
-//     k_rle_plan, so nothing here is serial;
+//   - one 1024-thread workgroup per CU walks over CHUNKS of the run plan that k_rle_plan_chunks
+//     made (up to 20480 consecutive values of a page, at most 231 run segments), so nothing here
+//     is serial and pages of any length or run count are handled;
 //   - a tile of up to 1024*R ids is unpacked into REGISTERS from packed dwords read straight from
 //     global memory (coalesced; each lane owns units of four consecutive values);
 //   - the dictionary streams through LDS in 64 KiB slices, double-buffered, by LDS-DMA
@@ -21,8 +22,8 @@
 //   - the values are stored once, 16 bytes per lane, fully coalesced.
 // HBM traffic per value: w/8 bytes of ids + ELEM bytes out; the slices are L2 traffic
 // (dictionary bytes per tile, i.e. a few bytes per value).  Small dictionaries (one slice) stay
-// resident across pages.  Pages this kernel is not made for (more than SEG_CHUNK segments, a
-// dictionary too large to sweep) are flagged by the plan kernel and left to the generic kernel.
+// resident across chunks.  Pages this kernel is not made for (ids wider than 16 bits, a dictionary
+// too large to sweep) are flagged by the plan kernel and left to the generic kernel.
 #include "pqd_device.hpp"
 #ifdef PQD_PROF
 #include <cstdio>
@@ -37,16 +38,13 @@ namespace pqd {
 constexpr int DS_THREADS = 1024;
 constexpr int DS_WAVES = DS_THREADS / 64;
 constexpr int DS_R = DS_TILE_VALUES / DS_THREADS;  // values per lane per tile
-constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;         // one page's segments
-constexpr int DS_PLAN_BYTES = 64;
+constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;         // one chunk of the plan: segments, header, block table
 
-constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;               // three segment buffers
-constexpr int DS_OFF_PLANS = DS_OFF_SEGS + 3 * DS_SEG_BYTES;  // three plan records
-constexpr int DS_OFF_STATE = DS_OFF_PLANS + 4 * DS_PLAN_BYTES;
+constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;  // three chunk buffers
+constexpr int DS_OFF_STATE = DS_OFF_SEGS + 3 * DS_SEG_BYTES;
 constexpr int DS_LDS_BYTES = DS_OFF_STATE + 64;
 static_assert(DS_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(DS_OFF_STATE % 16 == 0, "state block alignment");
-static_assert(sizeof(RlePagePlan) == DS_PLAN_BYTES, "plan record size");
 static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag bit per value");
 
 #define PQD_GLOBAL __attribute__((address_space(1)))
@@ -70,7 +68,7 @@ static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag b
 #endif
 
 struct DsShared {
-  uint32_t oob_at[3];  // first out-of-range id of the page in plan buffer 0 / 1 / 2
+  uint32_t oob_at[3];  // first out-of-range id (output index) of the chunk in buffer 0 / 1 / 2
   uint32_t pad;
 };
 
@@ -83,7 +81,10 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_re
 // behind the slice being prefetched into the OTHER buffer.  Completion is awaited explicitly in
 // wg_barrier().
 __device__ __forceinline__ void dma16(const void* gbase, uint32_t goff, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(goff), "s"(gbase)
+  // the base must sit in scalar registers whatever the compiler thinks of its uniformity
+  const uint64_t g = (uint64_t)(uintptr_t)gbase;
+  const uint64_t gs = ((uint64_t)uni((uint32_t)(g >> 32)) << 32) | uni((uint32_t)g);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(goff), "s"(gs)
                : "memory");
 }
 
@@ -119,19 +120,14 @@ __device__ __forceinline__ void load_slice(const uint8_t* slice_src, uint32_t by
   }
 }
 
-// A page's segments (1 KiB per wave, starting with wave 0; the segments of page p are pool chunk
-// p) and plan record (the next wave) into the LDS buffers `seg_buf` / `plan_buf` (LDS byte
-// addresses).
-__device__ __forceinline__ void fetch_plan_async(const RlePagePlan* plans, const RleSeg* pool, uint32_t page,
-                                                 uint32_t seg_buf, uint32_t plan_buf, uint32_t wave, uint32_t lane) {
-  if (wave < (uint32_t)(DS_SEG_BYTES / 1024)) {
-    dma16(pool + (size_t)page * SEG_CHUNK, wave * 1024 + lane * 16, uni(seg_buf + wave * 1024));
-  } else if (wave == (uint32_t)(DS_SEG_BYTES / 1024)) {
-    if (lane < (uint32_t)(DS_PLAN_BYTES / 16)) dma16(plans + page, lane * 16, uni(plan_buf));
-  }
+// One chunk of the plan (2 KiB: 1 KiB per wave, waves 0 and 1) into the LDS buffer at byte address `buf`.
+__device__ __forceinline__ void fetch_chunk_async(const RleSeg* pool, uint32_t chunk, uint32_t buf, uint32_t wave,
+                                                  uint32_t lane) {
+  if (wave < (uint32_t)(DS_SEG_BYTES / 1024))
+    dma16(pool + (size_t)chunk * SEG_CHUNK, wave * 1024 + lane * 16, uni(buf + wave * 1024));
 }
 
-// Page constants, read from the plan record in LDS and held in scalar registers.
+// Chunk constants, read from the chunk header in LDS and held in scalar registers.
 struct PageHead {
   const PQD_GLOBAL uint32_t* words;  // `data` rounded down to a dword
   const PQD_GLOBAL uint32_t* load_words;  // base of the 12-byte unit loads (`words`, or a harmless address)
@@ -139,28 +135,29 @@ struct PageHead {
   uint32_t max_wi;                   // largest dword index a 12-byte unit load may start at
   uint32_t full_words;               // dwords lying wholly before the end of the stream
   uint32_t tail_mask;                // valid bytes of dword `full_words` (0: none)
-  uint32_t n_out, w, nseg, flags;
-  bool no_fast;                      // no unit of this page can take the 12-byte path
+  uint32_t v0, v1, w;                // output values [v0, v1) of the page
+  bool no_fast;                      // no unit of this chunk can take the 12-byte path
 };
 
-// `spare` is any 12 readable bytes: what the unit loads read when a page gives them nothing to read.
-__device__ __forceinline__ PageHead read_head(const PQD_LDS RlePagePlan* pl, const void* spare) {
+// `spare` is any 12 readable bytes: what the unit loads read when there is nothing to read.
+// `valid` false: the buffer holds no chunk (none left); the head then describes an empty range.
+__device__ __forceinline__ PageHead read_head(const PQD_LDS RleSeg* chunk_buf, bool valid, const void* spare) {
+  const PQD_LDS RleChunkHead* hd = (const PQD_LDS RleChunkHead*)(chunk_buf + SEG_HEAD_SLOT);
   PageHead h;
-  const uint32_t dlo = uni((uint32_t)pl->data), dhi = uni((uint32_t)(pl->data >> 32));
+  const uint32_t dlo = uni((uint32_t)hd->data), dhi = uni((uint32_t)(hd->data >> 32));
   const uint64_t data = ((uint64_t)dhi << 32) | dlo;
   h.in_off = dlo & 3u;
   h.words = (const PQD_GLOBAL uint32_t*)(data - h.in_off);
-  const uint32_t data_len = uni(pl->data_len), stream_end = uni(pl->stream_end);
+  const uint32_t data_len = uni(hd->data_len), stream_end = uni(hd->stream_end);
   const uint32_t last_word = data_len ? (h.in_off + data_len - 1) >> 2 : 0u;  // last dword holding a byte of the page
   const uint32_t end_bytes = h.in_off + stream_end;
   h.full_words = end_bytes >> 2;
   h.tail_mask = (end_bytes & 3u) ? ((1u << (8 * (end_bytes & 3u))) - 1u) : 0u;
-  h.n_out = uni(pl->n_out);
-  h.w = uni(pl->w);
-  h.nseg = uni(pl->nseg);
-  h.flags = uni(pl->flags);
+  h.v0 = valid ? uni(hd->v0) : 0u;
+  h.v1 = valid ? uni(hd->v1) : 0u;
+  h.w = uni(hd->w);
   // ids of up to 16 bits: four of them, at any bit offset, lie inside three dwords
-  h.no_fast = last_word < 2 || h.w > 16 || (h.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) != 0 || h.n_out == 0;
+  h.no_fast = !valid || last_word < 2 || h.w > 16;
   h.max_wi = h.no_fast ? 0u : last_word - 2;
   h.load_words = h.no_fast ? (const PQD_GLOBAL uint32_t*)spare : h.words;
   return h;
@@ -173,17 +170,18 @@ struct UnitRaw {
 };
 constexpr uint32_t UK_NONE = 0, UK_PACKED = 1, UK_RLE = 2, UK_SLOW = 3;
 
-// For every unit (four consecutive values, unit k of lane t starts at value 4 * (k * 1024 + t)) of
-// the page's values [0, t1): find its segment, classify it and ISSUE the 12-byte load of its
+// For every unit (four consecutive values, unit k of lane t starts at value v0 + 4 * (k * 1024 + t))
+// of the chunk's values [v0, v1): find its segment, classify it and ISSUE the 12-byte load of its
 // packed dwords.  Nothing waits on the loads here (they complete behind the sweep of the page
 // before), and every lane issues every load (units with nothing to read take dwords 0..2): a load
 // whose destination is also written on another control-flow path would have to be waited for on
 // the spot.  Units that straddle segments, lie in a segment cut short by the end of the stream,
 // or hold ids wider than 16 bits are marked for the value-by-value path.
 template <int UNITS>
-__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t t1, const PageHead& h, uint32_t tid,
-                                             uint32_t wave, UnitRaw (&raw)[UNITS] PROF_FN_PARAM) {
+__device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, const PageHead& h, uint32_t tid, uint32_t wave,
+                                             UnitRaw (&raw)[UNITS] PROF_FN_PARAM) {
   const PQD_LDS uint8_t* table = (const PQD_LDS uint8_t*)(cs + SEG_TABLE_SLOT);
+  const uint32_t t1 = h.v1;
   const uint32_t t1x4 = t1 << 2;
   // Every step below is done for all units before the next one, so that a step costs one LDS
   // round trip for the lane, not one per unit.
@@ -198,7 +196,7 @@ __device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t 
     for (int k = 0; k < UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
-      const uint32_t g4 = 16 * ((uint32_t)k * DS_THREADS + tid) + 3;  // start4 <= g4  <=>  start <= g0
+      const uint32_t g4 = 4 * (h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid)) + 3;  // start4 <= g4  <=>  start <= g0
       sg[k] += nx[k] <= g4 ? 1u : 0u;                                 // valid lanes stop at the sentinel
     }
   }
@@ -209,7 +207,7 @@ __device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t 
     for (int k = 0; k < UNITS; ++k) nx[k] = cs[sg[k] + 1].start4;
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
-      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+      const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
       const bool adv = g0 < t1 && nx[k] <= g0 * 4 + 3;
       sg[k] += adv ? 1u : 0u;
       any |= adv;
@@ -225,7 +223,7 @@ __device__ __forceinline__ void locate_fetch(const PQD_LDS RleSeg* cs, uint32_t 
   }
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
-    const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+    const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
     const uint32_t lim4 = e4s[k] < t1x4 ? e4s[k] : t1x4;
     const bool is_packed = (sk[k] & SEG_PACKED_BIT) != 0;
     const bool whole = g0 * 4 + 16 <= lim4 && !(sk[k] & SEG_PARTIAL_BIT);
@@ -259,8 +257,9 @@ __device__ __forceinline__ uint32_t unit_value(uint32_t lo, uint32_t hi, uint32_
 
 // Turns the fetched dwords into ids (values at or beyond t1 become 0).
 template <int UNITS>
-__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t t1, const PageHead& h, uint32_t tid,
+__device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, const PageHead& h, uint32_t tid,
                                         const UnitRaw (&raw)[UNITS], uint32_t (&id)[UNITS * 4]) {
+  const uint32_t t1 = h.v1;
   const uint32_t w = h.w <= 16 ? h.w : 0u;  // wider ids never take the 12-byte path
   bool any_slow = false;
 #pragma unroll
@@ -293,14 +292,14 @@ __device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t t1, c
 #pragma unroll
       for (int kk = 0; kk < UNITS; ++kk) meta = kk == k ? raw[kk].meta : meta;  // k is not a compile-time constant
       if (((meta >> 8) & 3u) != UK_SLOW) continue;
-      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+      const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
       uint32_t t = meta >> 16;
       uint32_t v[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t g = g0 + j;
         if (g >= t1) continue;
-        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == n_out > g)
+        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
         const uint32_t tk = cs[t].start4, src = cs[t].src;
         if (tk & SEG_PACKED_BIT) {
           const uint32_t byte0 = h.in_off + src;
@@ -326,8 +325,8 @@ __device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, uint32_t t1, c
 
 template <int ELEM>
 __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_result* __restrict__ results,
-                                                                  const RlePagePlan* __restrict__ plans,
-                                                                  const RleSeg* __restrict__ pool, uint32_t n_pages PROF_PARAM) {
+                                                                  const RleSeg* __restrict__ pool, uint32_t pool_chunks,
+                                                                  const uint32_t* __restrict__ cursor, uint32_t n_pages PROF_PARAM) {
   extern __shared__ u32x4 lds4[];
   uint8_t* lds = reinterpret_cast<uint8_t*>(lds4);
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
@@ -346,44 +345,43 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   uint32_t res_win = ~0u;  // window mode: which window (0 / 1) the two buffers hold; ~0: none
   bool descending = false;  // slice order of the current page
 
-  uint32_t page = blockIdx.x;
-  if (page >= n_pages) return;
+  // chunks to take: one per page (empty ones included) and the extra ones the plan kernel took from
+  // the shared tail (it may have asked for more than the pool holds)
+  uint32_t n_chunks = n_pages + uni(*cursor);
+  if (n_chunks > pool_chunks) n_chunks = pool_chunks;
+  uint32_t chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
   const uint32_t stride = gridDim.x;
-  // Plan / segment buffers form a ring of three: the current page, the next one (its packed dwords
-  // are fetched while the current page is gathered) and the one after (its plan is on its way).
+  // Chunk buffers form a ring of three: the current chunk, the next one (its packed dwords are
+  // fetched while the current chunk is gathered) and the one after (it is on its way).
   uint32_t pb = 0;
-  fetch_plan_async(plans, pool, page, lds0 + DS_OFF_SEGS, lds0 + DS_OFF_PLANS, wave, lane);
-  if (page + stride < n_pages)
-    fetch_plan_async(plans, pool, page + stride, lds0 + DS_OFF_SEGS + DS_SEG_BYTES, lds0 + DS_OFF_PLANS + DS_PLAN_BYTES, wave,
-                     lane);
+  fetch_chunk_async(pool, chunk, lds0 + DS_OFF_SEGS, wave, lane);
+  if (chunk + stride < n_chunks) fetch_chunk_async(pool, chunk + stride, lds0 + DS_OFF_SEGS + DS_SEG_BYTES, wave, lane);
   if (tid < 3) sh->oob_at[tid] = ~0u;
   wg_barrier();
 
-  UnitRaw raw[UNITS];  // packed dwords of the page about to be decoded
+  UnitRaw raw[UNITS];  // packed dwords of the chunk about to be decoded
   PROF_INIT
   {
-    const PageHead h0 = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS), plans);
-    const bool ok = !(h0.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
-    locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), ok ? h0.n_out : 0u, h0, tid, wave, raw PROF_FN_ARG);
+    const PageHead h0 = read_head((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), true, pool);
+    locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS), h0, tid, wave, raw PROF_FN_ARG);
   }
 
   for (;;) {
     const uint32_t nb = pb == 2 ? 0u : pb + 1, nnb = nb == 2 ? 0u : nb + 1;
     const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + pb * DS_SEG_BYTES);
-    const PQD_LDS RlePagePlan* lpl = (const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + pb * DS_PLAN_BYTES);
-    const PageHead h = read_head(lpl, plans);
-    const bool skip = (h.flags & (PLAN_F_DONE | PLAN_F_FALLBACK)) != 0;
-    const uint32_t n_out = skip ? 0u : h.n_out;  // at most DS_TILE_VALUES (the plan kernel sees to it)
-    const uint32_t dict_len = uni(lpl->dict_len);
-    const uint64_t dict_addr = ((uint64_t)uni((uint32_t)(lpl->dict >> 32)) << 32) | uni((uint32_t)lpl->dict);
-    const uint64_t out_addr = ((uint64_t)uni((uint32_t)(lpl->out >> 32)) << 32) | uni((uint32_t)lpl->out);
-    const int32_t page_status = (int32_t)uni((uint32_t)lpl->status);
-    const uint32_t page_consumed = uni(lpl->consumed);
-    const uint32_t next_page = page + stride;
-    const bool has_next = next_page < n_pages;
-    const uint32_t P = n_out ? (dict_len + S - 1) / S : 0u;
+    const PQD_LDS RleChunkHead* hd = (const PQD_LDS RleChunkHead*)(cs + SEG_HEAD_SLOT);
+    const PageHead h = read_head(cs, true, pool);
+    const uint32_t v0 = h.v0, n_out = h.v1;  // output values [v0, n_out) of the page; at most DS_TILE_VALUES of them
+    const uint32_t dict_len = uni(hd->dict_len);
+    const uint64_t dict_addr = ((uint64_t)uni((uint32_t)(hd->dict >> 32)) << 32) | uni((uint32_t)hd->dict);
+    const uint64_t out_addr = ((uint64_t)uni((uint32_t)(hd->out >> 32)) << 32) | uni((uint32_t)hd->out);
+    const uint32_t page = uni(hd->page);
+    const uint32_t next_chunk = chunk + stride;
+    const bool has_next = next_chunk < n_chunks;
+    const uint32_t P = (dict_len + S - 1) / S;
     const uint8_t* dict_bytes = reinterpret_cast<const uint8_t*>(dict_addr);
-    if (n_out && dict_addr != tag_dict) {  // another dictionary: nothing resident is of use
+    if (dict_addr != tag_dict) {  // another dictionary: nothing resident is of use
       tag_dict = dict_addr;
       tag_s0 = tag_s1 = ~0u;
       res_win = ~0u;
@@ -392,7 +390,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
     // ---- 1. ids into registers (their packed dwords were requested one page ago)
     uint32_t id[R];
-    extract<UNITS>(cs, n_out, h, tid, raw, id);
+    extract<UNITS>(cs, h, tid, raw, id);
     PROF(1)
 
     // ---- 2. ids beyond the dictionary: note the first one, and look up entry 0 instead.
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
       uint32_t bad = ~0u;
 #pragma unroll
       for (int k = UNITS - 1; k >= 0; --k) {
-        const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+        const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
           const bool over = id[4 * k + j] >= dict_len;
@@ -475,20 +473,17 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
       PROF(9)
     }
 
-    // ---- 4. prefetch: the plan of the page after the next, the packed dwords of the next page.
+    // ---- 4. prefetch: the chunk after the next, the packed dwords of the next chunk.
     // The loads are issued unconditionally (from a harmless address when there is nothing to
     // fetch) so that exactly UNITS of them are this wave's most recent memory operations when it
     // reaches the next barrier.
-    if (next_page + stride < n_pages && next_page + stride >= next_page)
-      fetch_plan_async(plans, pool, next_page + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES,
-                       lds0 + DS_OFF_PLANS + nnb * DS_PLAN_BYTES, wave, lane);
+    if (next_chunk + stride < n_chunks && next_chunk + stride >= next_chunk)
+      fetch_chunk_async(pool, next_chunk + stride, lds0 + DS_OFF_SEGS + nnb * DS_SEG_BYTES, wave, lane);
     {
-      // without a next page this reads the stale record of an earlier page (or nothing fetched
-      // yet): only its load base is used, and read_head makes that harmless for unusable records
-      const PageHead nh = read_head((const PQD_LDS RlePagePlan*)(lds + DS_OFF_PLANS + nb * DS_PLAN_BYTES), plans);
-      const bool ok = has_next && !(nh.flags & (PLAN_F_DONE | PLAN_F_FALLBACK));
-      locate_fetch<UNITS>((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES), ok ? nh.n_out : 0u, nh, tid, wave,
-                          raw PROF_FN_ARG);
+      // without a next chunk the buffer holds stale bytes: read_head then describes an empty range
+      const PQD_LDS RleSeg* ncs = (const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS + nb * DS_SEG_BYTES);
+      const PageHead nh = read_head(ncs, has_next, pool);
+      locate_fetch<UNITS>(ncs, nh, tid, wave, raw PROF_FN_ARG);
     }
     PROF(8)
 
@@ -551,7 +546,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     // ---- 5. store, 16 bytes per lane per instruction
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
-      const uint32_t g0 = 4 * ((uint32_t)k * DS_THREADS + tid);
+      const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
       if (g0 >= n_out) continue;
       if (ELEM == 4) {
         PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
@@ -582,33 +577,28 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     }
     PROF(6)
 
-    // ---- 6. page end.  All atomicMin on this page's oob slot are in after the barrier; the slot is
-    // next used three pages on.  A page without a sweep has had no barrier that made sure the
-    // plan DMA issued above has landed: it takes the full one.
+    // ---- 6. chunk end.  All atomicMin on this chunk's oob slot are in after the barrier; the slot
+    // is next used three chunks on.  A chunk without a sweep has had no barrier that made sure the
+    // chunk DMA issued above has landed: it takes the full one.
     if (P == 0)
       wg_barrier();
     else if (wide && !two_windows)
-      wg_barrier_keep<UNITS>();  // the only barrier of such a page: waits for everything but this page's last stores
+      wg_barrier_keep<UNITS>();  // the only barrier of such a chunk: waits for everything but its last stores
     else
       wg_barrier_lds();
-    if (!skip && tid == 0) {
-      pqd_page_result r;
+    if (tid == 0) {
       const uint32_t oob = sh->oob_at[pb];
-      sh->oob_at[pb] = ~0u;
-      if (oob < n_out) {
-        r.status = PQD_DICT_OOB;
-        r.values_written = oob;
-      } else {
-        r.status = page_status;
-        r.values_written = n_out;
+      if (oob != ~0u) {
+        // the plan kernel wrote the page's result; an id beyond the dictionary comes before whatever
+        // ended the header walk.  Chunks of one page may report from different workgroups.
+        sh->oob_at[pb] = ~0u;
+        atomicMin(&results[page].values_written, oob);
+        results[page].status = PQD_DICT_OOB;
       }
-      r.bytes_consumed = page_consumed;
-      r.reserved = 0;
-      results[page] = r;
     }
     if (!has_next) break;
     pb = nb;
-    page = next_page;
+    chunk = next_chunk;
     PROF(7)
   }
 #ifdef PQD_PROF
@@ -640,9 +630,8 @@ static void prof_report(uint32_t grid, hipStream_t stream) {
 }
 #endif
 
-hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
-                                    const void* pool, uint32_t n_pages, int elem, hipStream_t stream) {
-  (void)descs;  // the plan records carry everything the kernel needs
+hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
+                                    uint32_t n_pages, int elem, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   if (g_cu_count == 0) {
     int dev = 0;
@@ -653,8 +642,9 @@ hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result*
     if (e != hipSuccess) return e;
     g_cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  // one persistent workgroup per CU; each takes chunks blockIdx.x, blockIdx.x + gridDim.x, ... of
+  // however many the plan kernel made (a count only the device knows)
   const uint32_t grid = n_pages < (uint32_t)g_cu_count ? n_pages : (uint32_t)g_cu_count;
-  const RlePagePlan* pp = reinterpret_cast<const RlePagePlan*>(plans);
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
   hipError_t e;
 #ifdef PQD_PROF
@@ -664,12 +654,12 @@ hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result*
     auto k = k_dict_pages_sliced<4>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages PROF_ARG);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
   } else {
     auto k = k_dict_pages_sliced<8>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, pp, sp, n_pages PROF_ARG);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
   }
 #ifdef PQD_PROF
   prof_report(grid, stream);

@@ -4,7 +4,7 @@
 // RunLengthBitPackingHybridDecoder.java:61-78) for every value of every page, but from the run plan
 // that k_rle_plan_chunks left in device memory (pqd_rle_plan.hpp), so nothing here is serial: a
 // chunk of the plan describes up to 32768 consecutive output values of one page by at most 231
-// run segments.  Workgroups take chunks from a shared counter until none are left; a lane owns
+// run segments.  Workgroups take chunks blockIdx.x, blockIdx.x + gridDim.x, ...; a lane owns
 // units of four consecutive values: it finds the unit's segment (block table + a short walk),
 // loads the unit's packed dwords with one or two loads, extracts the four values with funnel
 // shifts / bit-field extracts and stores them with one 16-byte store.
@@ -209,21 +209,17 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
 }
 
 __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restrict__ pool, uint32_t pool_chunks,
-                                                           const uint32_t* __restrict__ cursor,
-                                                           uint32_t* __restrict__ next_chunk) {
+                                                           const uint32_t* __restrict__ cursor, uint32_t n_pages) {
   __shared__ RleSeg cs_buf[SEG_CHUNK];
-  __shared__ uint32_t s_chunk;
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = uni(tid >> 6);
-  uint32_t n_chunks = *cursor;  // chunks the plan kernel allocated (it may have asked for more than there are)
+  // chunks to take: one per page (empty ones included) and the extra ones the plan kernel took from
+  // the shared tail (it may have asked for more than the pool holds)
+  uint32_t n_chunks = n_pages + uni(*cursor);
   if (n_chunks > pool_chunks) n_chunks = pool_chunks;
   const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)cs_buf;
-  for (;;) {
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     __syncthreads();  // everybody is done with the previous chunk
-    if (tid == 0) s_chunk = atomicAdd(next_chunk, 1u);
-    __syncthreads();
-    const uint32_t c = s_chunk;
-    if (c >= n_chunks) break;
     {
       const PQD_GLOBAL uint64_t* src = (const PQD_GLOBAL uint64_t*)(pool + (size_t)c * SEG_CHUNK);
       ((PQD_LDS uint64_t*)cs_buf)[tid] = src[tid];  // SEG_CHUNK == EX_THREADS slots of 8 bytes
@@ -254,8 +250,9 @@ __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restr
 
 static int g_ex_cu_count = 0;
 
-hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* next_chunk,
+hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
   if (g_ex_cu_count == 0) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -266,7 +263,7 @@ hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint3
     g_ex_cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   hipLaunchKernelGGL(k_rle_expand, dim3((uint32_t)g_ex_cu_count * 8), dim3(EX_THREADS), 0, stream,
-                     reinterpret_cast<const RleSeg*>(pool), pool_chunks, cursor, next_chunk);
+                     reinterpret_cast<const RleSeg*>(pool), pool_chunks, cursor, n_pages);
   return hipGetLastError();
 }
 

@@ -414,12 +414,29 @@ __device__ __forceinline__ void plan_round(PlanState& st, u32x4* win4, RleSeg* s
   __syncthreads();
 }
 
-__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* __restrict__ descs,
-                                                           pqd_page_result* __restrict__ results,
-                                                           RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
-                                                           uint32_t n_pages, int want_dict, int elem) {
+// Pool chunk p is reserved for page p; a page that has nothing for the consuming kernel leaves an
+// empty chunk there (v0 == v1), so that the consumers can take every slot as it comes.
+__device__ __forceinline__ void write_empty_chunk(RleSeg* pool, uint32_t page) {
+  RleChunkHead hd = {};
+  hd.data = (uint64_t)(uintptr_t)pool;  // any readable address
+  hd.page = page;
+  *reinterpret_cast<RleChunkHead*>(pool + (size_t)page * SEG_CHUNK + SEG_HEAD_SLOT) = hd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The plan kernel: one wave per page, pages of any length.  The plan is a list of chunks taken from
+// a shared pool (pqd_rle_plan.hpp): plain hybrid pages (want_dict == 0: levels, booleans, ids as
+// ints) are consumed by k_rle_expand, dictionary pages (want_dict == 1) by k_dict_pages_sliced,
+// whose workgroup holds a whole chunk in registers (hence the smaller span).  The page's result
+// is written here; the dictionary kernel amends it if it meets an id beyond the dictionary.
+__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page_desc* __restrict__ descs,
+                                                                  pqd_page_result* __restrict__ results,
+                                                                  RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
+                                                                  uint32_t pool_chunks, uint32_t* __restrict__ cursor,
+                                                                  uint32_t n_pages, int want_dict, int elem) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
+  __shared__ RleSeg chunk[SEG_CHUNK];
   __shared__ u32x4 nxt4[PLAN_WINDOW / 8], list4[PLAN_WINDOW / 8];
   __shared__ PlanState st;
   uint16_t* nxt = reinterpret_cast<uint16_t*>(nxt4);
@@ -482,201 +499,29 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan(const pqd_page_desc* 
       RlePagePlan pl = {};
       pl.status = early;
       pl.flags = PLAN_F_DONE;
-      pl.w = w;
       plans[page] = pl;
+      if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
   }
-
-  // segment start indices hold 30 bits; the sliced dictionary kernel holds a whole page in its
-  // registers and reads ids of up to 16 bits: leave other pages to the generic kernel
-  if (n_values > SEG_START_MAX || (want_dict && (n_values > DS_TILE_VALUES || w > 16))) {
+  // Not for the planned kernels: pages of more than 2^30 values (segment starts hold 30 bits);
+  // dictionary pages with ids wider than 16 bits, or whose dictionary is misaligned or too large
+  // for streaming it through LDS to be cheaper than a direct gather.
+  bool not_planned = n_values > SEG_START_MAX;
+  if (want_dict) {
+    const uint32_t per_slice = DS_SLICE_BYTES / (uint32_t)elem;
+    const uint32_t passes = (d.dict_len + per_slice - 1) / per_slice;
+    const uint32_t held = n_values < DS_TILE_VALUES ? n_values : DS_TILE_VALUES;
+    const bool sweepable = ((uintptr_t)d.dict & 15u) == 0 &&
+                           (passes <= 1 || (passes <= DS_MAX_PASSES && (uint64_t)d.dict_len * (uint32_t)elem <= 32ull * held));
+    not_planned = not_planned || w > 16 || !sweepable;
+  }
+  if (not_planned) {
     if (tid == 0) {
       RlePagePlan pl = {};
       pl.flags = PLAN_F_FALLBACK;
       plans[page] = pl;
-    }
-    return;
-  }
-  if (tid == 0) {
-    st.pos = pos;
-    st.vals = 0;
-    st.pending = 0;
-    st.nstage = 0;
-    st.status = PQD_OK;
-    st.done = 0;
-    st.need_round = 1;
-    st.round_pos0 = pos;
-    st.round_stride = 16;
-    st.next_stride = 16;
-    st.prev_stride = 16;
-    st.chunk_slot = 0;
-  }
-  __syncthreads();
-
-    const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
-  uint32_t nseg = 0;
-  bool fallback = false;
-  for (;;) {
-    bool fresh = false;
-    if (st.need_round) {
-      plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
-      fresh = true;
-    }
-    // a fresh contiguous window is planned by all lanes; the serial walk takes only what that leaves
-    const bool windowed = fresh && st.round_stride == 16 && st.pending == 0 && !st.done && st.nstage <= (uint32_t)SEG_MAX;
-    if (windowed) plan_window(st, win4, nxt, list, stage, end, w, n_values, (uint32_t)SEG_MAX + 1, tid);
-    if (tid == 0 && !st.need_round && !st.done)
-      plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_MAX + 1, windowed ? 1u : ~0u);
-    __syncthreads();
-    const uint32_t ns = st.nstage;
-    const bool done = st.done != 0;
-    if (ns > (uint32_t)SEG_MAX) {  // more segments than a planned page may have
-      fallback = true;
-      break;
-    }
-    if (done) {
-      const uint32_t n_out = st.vals;
-      if (tid == 0) stage[ns].start4 = n_out << 2;  // sentinel
-      __syncthreads();
-      // block table: the segment holding value SEG_BLOCK * b (lower-bound search, one block per lane and turn)
-      uint8_t* table = reinterpret_cast<uint8_t*>(stage + SEG_TABLE_SLOT);
-      for (uint32_t b = tid; b < (uint32_t)SEG_TABLE_BLOCKS; b += PLAN_THREADS) {
-        const uint32_t first = b * SEG_BLOCK;
-        uint32_t lo = 0, hi = ns;  // start[lo] <= first < start[hi]
-        if (first >= n_out) {
-          lo = ns ? ns - 1 : 0;
-        } else {
-          while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((stage[mid].start4 >> 2) <= first)
-              lo = mid;
-            else
-              hi = mid;
-          }
-        }
-        table[b] = (uint8_t)lo;
-      }
-      __syncthreads();
-      // the chunk of page p is pool chunk p: segments + sentinel, and the table
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(stage);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (size_t)page * SEG_CHUNK);
-      for (uint32_t i = tid; i < (ns + 1) * 2; i += PLAN_THREADS) dst[i] = src[i];
-      for (uint32_t i = SEG_TABLE_SLOT * 2 + tid; i < (uint32_t)SEG_CHUNK * 2; i += PLAN_THREADS) dst[i] = src[i];
-      nseg = ns;
-      break;
-    }
-  }
-  if (tid == 0) {
-    const uint32_t n_out = st.vals;
-    if (want_dict && !fallback) {
-      // is streaming the dictionary through LDS cheaper than a direct gather for this page?
-      const uint32_t per_slice = DS_SLICE_BYTES / (uint32_t)elem;
-      const uint32_t passes = (d.dict_len + per_slice - 1) / per_slice;
-      const uint32_t held = n_out < DS_TILE_VALUES ? n_out : DS_TILE_VALUES;
-      const bool sweepable = ((uintptr_t)d.dict & 15u) == 0 &&
-                             (passes <= 1 || (passes <= DS_MAX_PASSES && (uint64_t)d.dict_len * (uint32_t)elem <= 32ull * held));
-      if (!sweepable) fallback = true;
-    }
-    RlePagePlan pl = {};
-    pl.status = st.status;
-    pl.n_out = n_out;
-    pl.consumed = consumed_override != ~0u ? consumed_override : st.pos;
-    pl.nseg = nseg;
-    pl.w = w;
-    pl.flags = fallback ? PLAN_F_FALLBACK : 0u;
-    pl.stream_end = end;  // bytes at or past it read as zero
-    pl.data_len = d.data_len;
-    pl.data = (uint64_t)(uintptr_t)d.data;
-    pl.out = (uint64_t)(uintptr_t)d.out;
-    pl.dict = (uint64_t)(uintptr_t)d.dict;
-    pl.dict_len = d.dict_len;
-    plans[page] = pl;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same walk for plain hybrid pages (PQD_ENC_RLE: levels, booleans, ids as ints) of any length:
-// the plan is a list of chunks taken from a shared pool (pqd_rle_plan.hpp), consumed by
-// k_rle_expand.  The page's result is final here (nothing downstream can fail).
-__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page_desc* __restrict__ descs,
-                                                                  pqd_page_result* __restrict__ results,
-                                                                  RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
-                                                                  uint32_t pool_chunks, uint32_t* __restrict__ cursor,
-                                                                  uint32_t n_pages) {
-  __shared__ u32x4 win4[PLAN_SLOTS + 1];
-  __shared__ RleSeg stage[SEG_CHUNK];
-  __shared__ RleSeg chunk[SEG_CHUNK];
-  __shared__ u32x4 nxt4[PLAN_WINDOW / 8], list4[PLAN_WINDOW / 8];
-  __shared__ PlanState st;
-  uint16_t* nxt = reinterpret_cast<uint16_t*>(nxt4);
-  uint16_t* list = reinterpret_cast<uint16_t*>(list4);
-  const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
-  const uint32_t page = blockIdx.x;
-  if (page >= n_pages) return;
-  const pqd_page_desc d = descs[page];
-  const uint32_t tid = threadIdx.x;
-
-  // ---- validation and stream prefixes (same rules as the generic kernel)
-  int32_t early = PQD_OK;
-  bool finished = false;
-  uint32_t pos = 0, end = d.data_len, w = d.bit_width, consumed_override = ~0u;
-  const uint32_t n_values = d.num_values;
-  if (d.encoding != PQD_ENC_RLE || d.elem_size != 4) {
-    early = PQD_BAD_ARG;
-    finished = true;
-  } else if (d.flags & PQD_F_WIDTH_PREFIX) {
-    if (end == 0) {
-      early = n_values ? PQD_DECODE : PQD_OK;
-      finished = true;
-    } else {
-      w = d.data[0];
-      pos = 1;
-    }
-  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
-    if (end < 4) {
-      early = PQD_EOF;
-      finished = true;
-    } else {
-      const uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) |
-                           ((uint32_t)d.data[3] << 24);
-      if ((int32_t)len < 0) {
-        early = PQD_DECODE;
-        finished = true;
-      } else if (len > end - 4) {
-        early = PQD_EOF;
-        finished = true;
-      } else {
-        pos = 4;
-        end = 4 + len;
-        consumed_override = end;
-      }
-    }
-  }
-  if (!finished && w > 32) {
-    early = PQD_BAD_ARG;
-    finished = true;
-  }
-  if (finished || n_values == 0) {
-    if (tid == 0) {
-      pqd_page_result r;
-      r.status = early;
-      r.values_written = 0;
-      r.bytes_consumed = early == PQD_OK ? (consumed_override != ~0u ? consumed_override : pos) : 0;
-      r.reserved = 0;
-      results[page] = r;
-      RlePagePlan pl = {};
-      pl.status = early;
-      pl.flags = PLAN_F_DONE;
-      plans[page] = pl;
-    }
-    return;
-  }
-  if (n_values > SEG_START_MAX) {  // segment start indices hold 30 bits
-    if (tid == 0) {
-      RlePagePlan pl = {};
-      pl.flags = PLAN_F_FALLBACK;
-      plans[page] = pl;
+      if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
   }
@@ -698,6 +543,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
 
   const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
   uint32_t v0 = 0;  // start of the chunk being collected
+  uint32_t emitted = 0;  // chunks written for this page
+  const uint32_t span = want_dict ? DS_TILE_VALUES : SEG_CHUNK_SPAN;  // values per chunk, at most
   bool fallback = false;
   for (;;) {
     bool fresh = false;
@@ -715,8 +562,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
     const uint32_t vals = st.vals;
     uint32_t ns = st.nstage;
     // ---- cut chunks off the front of the stage while there is reason to
-    while (!fallback && (done ? v0 < vals : (ns >= (uint32_t)SEG_GEN_MAX || vals - v0 >= SEG_CHUNK_SPAN))) {
-      uint32_t v1 = vals - v0 > SEG_CHUNK_SPAN ? v0 + SEG_CHUNK_SPAN : vals;
+    while (!fallback && (done ? v0 < vals : (ns >= (uint32_t)SEG_GEN_MAX || vals - v0 >= span))) {
+      uint32_t v1 = vals - v0 > span ? v0 + span : vals;
       if (!(done && v1 == vals)) v1 &= ~(uint32_t)(SEG_BLOCK - 1);
       if (v1 <= v0) {  // more than SEG_GEN_MAX runs inside one block of values: not for this path
         fallback = true;
@@ -736,7 +583,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
         k = hi;
       }
       if (tid == 0) {
-        uint32_t slot = atomicAdd(cursor, 1u);
+        // the first chunk of page p is pool chunk p (thousands of pages asking one counter for a slot
+        // at the same time would queue up behind each other); further chunks come from the shared tail
+        uint32_t slot = emitted == 0 ? page : n_pages + atomicAdd(cursor, 1u);
         st.chunk_slot = slot < pool_chunks ? slot : ~0u;
       }
       __syncthreads();
@@ -759,6 +608,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
         hd->data_len = d.data_len;
         hd->stream_end = end;
         hd->page = page;
+        hd->dict = (uint64_t)(uintptr_t)d.dict;
+        hd->dict_len = d.dict_len;
       }
       __syncthreads();
       uint8_t* table = reinterpret_cast<uint8_t*>(chunk + SEG_TABLE_SLOT);
@@ -798,6 +649,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
       }
       ns = left;
       v0 = v1;
+      ++emitted;
     }
     __syncthreads();
     if (tid == 0) st.nstage = ns;
@@ -805,6 +657,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
     if (done || fallback) break;
   }
   if (tid == 0) {
+    if (emitted == 0 && page < pool_chunks) write_empty_chunk(pool, page);
     RlePagePlan pl = {};
     pl.flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
     plans[page] = pl;
@@ -820,18 +673,11 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
 }
 
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, hipStream_t stream) {
+                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
+                                  hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
-                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages);
-  return hipGetLastError();
-}
-
-hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                           uint32_t n_pages, bool want_dict, int elem, hipStream_t stream) {
-  if (n_pages == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rle_plan, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
-                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), n_pages,
+                     reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
                      want_dict ? 1 : 0, elem);
   return hipGetLastError();
 }

@@ -80,7 +80,7 @@ struct PlanScratch {
   uint32_t cap_pages = 0;
   void* gen_pool = nullptr;    // plain hybrid pages: chunks handed out through counters[0]
   uint32_t gen_chunks = 0;
-  uint32_t* counters = nullptr;  // [0] chunks allocated by the plan kernel, [1] chunks taken by the expansion kernel
+  uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool
 };
 std::mutex g_plan_mutex;
 std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
@@ -410,8 +410,8 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         int st = plan_scratch_general(s, n_pages, &ps);
         if (st) return st;
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, s));
-        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, ps.gen_chunks, ps.counters, ps.counters + 1, s));
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, false, 4, s));
+        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, s));
       }
       return PQD_OK;
@@ -420,16 +420,18 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
       if (!use_sliced_dictionary_path()) {
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, nullptr, s));
       } else {
-        // 1. header walk of every page (one wave per page) -> run plans in scratch
-        // 2. expansion + sliced LDS gather of the planned pages
-        // 3. generic kernel for the pages whose plan did not fit the scratch
+        // 1. header walk of every page (one wave per page) -> chunks of run segments in the pool
+        // 2. expansion + sliced LDS gather, chunk by chunk
+        // 3. generic kernel for the pages the plan left over
         PlanScratch ps;
-        int st = plan_scratch_for(s, n_pages, &ps);
+        int st = plan_scratch_general(s, n_pages, &ps);
         if (st) return st;
+        PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
         if ((st = phase_mark(0, s))) return st;
-        PQD_HIP(pqd::launch_rle_plan(descs, results, ps.plans, ps.pool, n_pages, true, elem_size, s));
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, true,
+                                            elem_size, s));
         if ((st = phase_mark(1, s))) return st;
-        PQD_HIP(pqd::launch_dict_pages_sliced(descs, results, ps.plans, ps.pool, n_pages, elem_size, s));
+        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, elem_size, s));
         if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, s));
         if ((st = phase_mark(3, s))) return st;

@@ -18,16 +18,15 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
                             bool has_dict, const void* only_fallback_plans, hipStream_t stream);
 // header walk -> run plans (pqd_rle_plan.hpp); `plans` holds n_pages records of 128 bytes, `pool`
 // pool_chunks chunks of 128 segments of 12 bytes, `pool_cursor` a zeroed counter
-hipError_t launch_rle_plan(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                           uint32_t n_pages, bool want_dict, int elem, hipStream_t stream);
 // plain hybrid pages: header walk into pool chunks, then expansion of all chunks
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
-                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, hipStream_t stream);
-hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* next_chunk,
+                                  uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
+                                  hipStream_t stream);
+hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather
-hipError_t launch_dict_pages_sliced(const pqd_page_desc* descs, pqd_page_result* results, const void* plans,
-                                    const void* pool, uint32_t n_pages, int elem, hipStream_t stream);
+hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
+                                    uint32_t n_pages, int elem, hipStream_t stream);
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream);
 hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,

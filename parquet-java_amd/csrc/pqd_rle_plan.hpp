@@ -51,7 +51,9 @@ struct RleChunkHead {
   uint32_t data_len;
   uint32_t stream_end;  // bytes at or past it read as zero
   uint32_t page;
-  uint32_t reserved[5];
+  uint32_t dict_len;    // dictionary pages: entries of the dictionary ...
+  uint64_t dict;        // ... and where it is
+  uint32_t reserved[2];
 };
 static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
 
