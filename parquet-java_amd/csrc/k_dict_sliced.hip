@@ -349,9 +349,13 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   // the shared tail (it may have asked for more than the pool holds)
   uint32_t n_chunks = n_pages + uni(*cursor);
   if (n_chunks > pool_chunks) n_chunks = pool_chunks;
-  uint32_t chunk = blockIdx.x;
+  // every workgroup takes one contiguous share of the chunks, so that at any moment the workgroups
+  // are spread over the whole batch
+  const uint32_t share = (n_chunks + gridDim.x - 1) / gridDim.x;
+  uint32_t chunk = blockIdx.x * share;
   if (chunk >= n_chunks) return;
-  const uint32_t stride = gridDim.x;
+  n_chunks = chunk + share < n_chunks ? chunk + share : n_chunks;  // from here on: the end of this workgroup's share
+  const uint32_t stride = 1;
   // Chunk buffers form a ring of three: the current chunk, the next one (its packed dwords are
   // fetched while the current chunk is gathered) and the one after (it is on its way).
   uint32_t pb = 0;
