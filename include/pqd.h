@@ -168,6 +168,90 @@ int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint3
  */
 int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result);
 
+/* ---- dictionaries ----------------------------------------------------------------------------- */
+/* org.apache.parquet.format.Type numbering (PrimitiveTypeName of the column). */
+enum pqd_physical_type {
+  PQD_TYPE_INT32 = 1,
+  PQD_TYPE_INT64 = 2,
+  PQD_TYPE_INT96 = 3,
+  PQD_TYPE_FLOAT = 4,
+  PQD_TYPE_DOUBLE = 5,
+  PQD_TYPE_BYTE_ARRAY = 6,
+  PQD_TYPE_FIXED_LEN_BYTE_ARRAY = 7
+};
+
+/* A view of one BINARY value, as Binary.fromConstantByteBuffer(dictionaryBytes, offset, length)
+ * holds it: low 32 bits = offset of its first byte in the dictionary page, high 32 bits = length. */
+#define PQD_VIEW_INVALID 0xffffffffffffffffULL /* an entry that fails when it is read (see below) */
+
+/*
+ * HOST: walks a PLAIN dictionary page of BYTE_ARRAY entries ([length: 4 bytes LE][bytes] ..., or
+ * fixed_length bytes each when fixed_length > 0: FIXED_LEN_BYTE_ARRAY, INT96 = 12) and writes one
+ * view per entry.  Replaces the constructor PlainBinaryDictionary(dictionaryPage, length)
+ * (parquet-column/.../values/dictionary/PlainValuesDictionary.java:88-115).  Like the reference it
+ * reads every length prefix (one outside the page -> PQD_DECODE, Java: IndexOutOfBoundsException)
+ * but does not look at the value bytes: an entry that runs past the page or has a negative length
+ * becomes PQD_VIEW_INVALID and fails only when a page refers to it.
+ */
+int pqd_binary_dict_views(const uint8_t* page, size_t page_len, uint32_t n_entries, int fixed_length,
+                          uint64_t* views);
+
+/*
+ * Dictionary handle: the decoded dictionary page, resident on the current device.  Replaces
+ * Encoding.PLAIN.initDictionary(descriptor, dictionaryPage) (parquet-column/.../Encoding.java:89-112)
+ * -> PlainValuesDictionary.Plain{Integer,Long,Float,Double,Binary}Dictionary
+ * (PlainValuesDictionary.java:59-345).  `page` is the HOST dictionary page body, n_entries its
+ * dictionarySize.  INT32/FLOAT/INT64/DOUBLE: entries are the 4-/8-byte values (a page shorter than
+ * n_entries values -> PQD_DECODE).  BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY (type_length) / INT96:
+ * entries are 8-byte views into `bytes`, the page body.  Synchronous.
+ */
+typedef struct pqd_dict pqd_dict;
+typedef struct pqd_dict_info {
+  const void* entries;  /* DEVICE: n_entries elements of elem_size bytes -> pqd_page_desc.dict        */
+  const uint8_t* bytes; /* DEVICE: the dictionary page body (BINARY kinds), else NULL                 */
+  uint32_t n_entries;   /* -> pqd_page_desc.dict_len; Dictionary.getMaxId() + 1                       */
+  uint32_t elem_size;   /* 4 or 8 -> pqd_page_desc.elem_size                                          */
+  uint32_t bytes_len;
+  uint32_t physical_type;
+} pqd_dict_info;
+int pqd_dict_create(int physical_type, int type_length, const uint8_t* page, size_t page_len, uint32_t n_entries,
+                    pqd_dict** dict);
+int pqd_dict_get(const pqd_dict* dict, pqd_dict_info* info);
+int pqd_dict_destroy(pqd_dict* dict);
+
+/*
+ * BINARY values of a page, gathered: replaces the loop `Binary b = reader.readBytes(); copy b`
+ * (DictionaryValuesReader.readBytes, parquet-column/.../values/dictionary/DictionaryValuesReader.java:76-83,
+ * Dictionary.decodeToBinary) for a page whose values are already known as views (a
+ * PQD_ENC_RLE_DICTIONARY decode with elem_size 8 and the dictionary's views as `dict`, which is the
+ * reference's own zero-copy result).  offsets[i] = start of value i in `bytes`,
+ * offsets[values_written] = end of the last value delivered (= result.bytes_consumed).
+ * PQD_DECODE at the first value whose view is PQD_VIEW_INVALID or outside dict_bytes; PQD_BAD_ARG at
+ * the first value that does not fit into bytes_capacity (at most 2^31-1 bytes per page: the offsets
+ * are Java ints).  All pointers are DEVICE pointers.
+ */
+typedef struct pqd_binary_page_desc {
+  const uint64_t* views;     /* num_values views                                                   */
+  const uint8_t* dict_bytes; /* the dictionary page body the views point into                      */
+  int32_t* offsets;          /* num_values + 1                                                     */
+  uint8_t* bytes;            /* bytes_capacity                                                     */
+  uint32_t num_values;
+  uint32_t dict_bytes_len;
+  uint32_t bytes_capacity;
+  uint32_t reserved;
+} pqd_binary_page_desc;
+int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
+                               void* stream);
+/*
+ * One BINARY dictionary data page, everything but the dictionary in HOST memory (what a Java
+ * DictionaryValuesReader over a PlainBinaryDictionary calls from initFromPage): decodes the ids,
+ * gathers the views and the bytes, copies offsets[0..values_written] and the bytes back.  The
+ * status is that of the first value that fails, in value order (PQD_PAST_END, PQD_DICT_OOB,
+ * PQD_DECODE, PQD_BAD_ARG); the values before it are delivered.
+ */
+int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
+                           int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ def _declare(L):
     L.orc_delta_encode_i64.restype = C.c_long
     L.orc_delta_encode_i32.argtypes = [_i32p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t]
     L.orc_delta_encode_i32.restype = C.c_long
+    L.orc_binary_dict_views.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]
+    L.orc_binary_materialize.argtypes = [C.c_void_p, C.c_size_t, _u8p, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp]
     L.orc_bss_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_size_t, _u8p, _szp]
     L.orc_bss_encode.argtypes = [_u8p, C.c_size_t, C.c_int, _u8p]
     L.orc_bss_encode.restype = None
@@ -174,6 +176,39 @@ def dict_decode(page, dictionary, n):
                                d.size, d.dtype.itemsize, out.ctypes.data_as(C.c_void_p) if n else None,
                                n, C.byref(wr))
     return st, out[:wr.value]
+
+
+# ---------------------------------------------------------------- BINARY dictionaries
+VIEW_INVALID = 0xFFFFFFFFFFFFFFFF
+
+
+def binary_dict_page(values):
+    """PLAIN-encoded BYTE_ARRAY dictionary page body: [len LE32][bytes] per entry
+    (PlainValuesWriter.writeBytes as used by PlainBinaryDictionaryValuesWriter.toDictPageAndClose)."""
+    out = bytearray()
+    for v in values:
+        out += len(v).to_bytes(4, "little") + bytes(v)
+    return np.frombuffer(bytes(out), np.uint8).copy()
+
+
+def binary_dict_views(page, n, fixed_length=0):
+    page = _u8(page)
+    views = np.zeros(n, np.uint64)
+    st = lib().orc_binary_dict_views(_p(page, _u8p), page.size, n, fixed_length,
+                                     views.ctypes.data_as(C.c_void_p))
+    return st, views
+
+
+def binary_materialize(views, dict_bytes, cap):
+    views = np.ascontiguousarray(views, np.uint64)
+    dict_bytes = _u8(dict_bytes)
+    offsets = np.zeros(views.size + 1, np.int32)
+    out = np.zeros(max(cap, 1), np.uint8)
+    wr, bw = C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_binary_materialize(views.ctypes.data_as(C.c_void_p), views.size, _p(dict_bytes, _u8p),
+                                      dict_bytes.size, _p(offsets, _i32p), _p(out, _u8p), cap,
+                                      C.byref(wr), C.byref(bw))
+    return st, offsets[:wr.value + 1], out[:bw.value]
 
 
 # ---------------------------------------------------------------- delta

@@ -878,3 +878,67 @@ int orc_bitpacked_levels_decode(int w, const uint8_t* in, size_t in_len, int32_t
   if (consumed) *consumed = length; /* updateNextOffset(length) */
   return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* BINARY / FIXED_LEN_BYTE_ARRAY / INT96 dictionaries                          */
+/* COL/values/dictionary/PlainValuesDictionary.java:88-115 (PlainBinaryDictionary), selected by        */
+/* COL/Encoding.java:89-112 (BINARY: length-prefixed; FLBA: typeLength; INT96: 12)                     */
+/* ------------------------------------------------------------------------- */
+
+/* A view = what Binary.fromConstantByteBuffer(dictionaryBytes, offset, len) holds: the low word is
+ * the offset of the first byte in the dictionary page, the high word the length.  The Java object is
+ * created without looking at the bytes, so an entry that runs past the page (or has a negative
+ * length) only fails when it is read: such entries get ORC_VIEW_INVALID.  The 4-byte length prefix
+ * itself is read eagerly (:97), outside the page that is an IndexOutOfBoundsException -> ORC_DECODE. */
+int orc_binary_dict_views(const uint8_t* page, size_t len, size_t n, int fixed_length, uint64_t* views) {
+  int64_t offset = 0;
+  if (fixed_length < 0) return ORC_BAD_ARG; /* Preconditions.checkArgument(length > 0), :107 */
+  for (size_t i = 0; i < n; ++i) {
+    int32_t l;
+    if (fixed_length == 0) {
+      if (offset < 0 || (uint64_t)offset + 4 > len) return ORC_DECODE; /* readIntLittleEndian, :97 */
+      l = (int32_t)((uint32_t)page[offset] | ((uint32_t)page[offset + 1] << 8) |
+                    ((uint32_t)page[offset + 2] << 16) | ((uint32_t)page[offset + 3] << 24));
+      offset += 4; /* :99 */
+    } else {
+      l = fixed_length;
+    }
+    if (l < 0 || offset < 0 || (uint64_t)offset + (uint64_t)l > len || offset > 0x7fffffff)
+      views[i] = ORC_VIEW_INVALID;
+    else
+      views[i] = ((uint64_t)(uint32_t)l << 32) | (uint32_t)offset;
+    offset += l; /* :103, :112 (Java int arithmetic; a negative length walks backwards) */
+    if (offset > 0x7fffffffLL || offset < -0x80000000LL) return ORC_DECODE; /* would wrap a Java int: treated as malformed */
+  }
+  return ORC_OK;
+}
+
+/* The read loop `for i: Binary b = reader.readBytes(); out.write(b.getBytes())` over a dictionary
+ * page whose ids were already turned into views (DictionaryValuesReader.readBytes,
+ * COL/values/dictionary/DictionaryValuesReader.java:76-83 -> Dictionary.decodeToBinary), gathered
+ * into one buffer: offsets[i] = position of value i, offsets[written] = end of the last one. */
+int orc_binary_materialize(const uint64_t* views, size_t n, const uint8_t* dict_bytes, size_t dict_len,
+                           int32_t* offsets, uint8_t* bytes, size_t cap, size_t* written, size_t* bytes_written) {
+  size_t pos = 0, i = 0;
+  int st = ORC_OK;
+  if (cap > 0x7fffffff) cap = 0x7fffffff; /* int32 offsets */
+  for (; i < n; ++i) {
+    uint64_t v = views[i];
+    uint32_t off = (uint32_t)v, l = (uint32_t)(v >> 32);
+    if (l == 0xffffffffu || (uint64_t)off + l > dict_len) {
+      st = ORC_DECODE;
+      break;
+    }
+    if (pos + l > cap) {
+      st = ORC_BAD_ARG;
+      break;
+    }
+    offsets[i] = (int32_t)pos;
+    memcpy(bytes + pos, dict_bytes + off, l);
+    pos += l;
+  }
+  offsets[i] = (int32_t)pos;
+  if (written) *written = i;
+  if (bytes_written) *bytes_written = pos;
+  return st;
+}

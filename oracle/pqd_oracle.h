@@ -67,6 +67,15 @@ int orc_dict_decode(const uint8_t* page, size_t len, const void* dict, size_t di
                     int elem_size, void* out, size_t n, size_t* written);
 long orc_dict_encode_ids(const int32_t* ids, size_t n, size_t dict_n, uint8_t* out, size_t cap);
 
+/* ---- BINARY / FLBA / INT96 dictionaries (PlainValuesDictionary.java:88-115): entries as views
+ * {low word: offset into the dictionary page, high word: length}; fixed_length 0 = length-prefixed */
+#define ORC_VIEW_INVALID 0xffffffffffffffffULL /* an entry that only fails when it is read */
+int orc_binary_dict_views(const uint8_t* page, size_t len, size_t n, int fixed_length, uint64_t* views);
+/* readBytes() over n values whose views are known, gathered into offsets[n+1] + bytes */
+int orc_binary_materialize(const uint64_t* views, size_t n, const uint8_t* dict_bytes, size_t dict_len,
+                           int32_t* offsets, uint8_t* bytes, size_t cap, size_t* written,
+                           size_t* bytes_written);
+
 /* ---- DELTA_BINARY_PACKED (DeltaBinaryPackingValuesReader.java:60-172) */
 int orc_delta_decode(const uint8_t* in, size_t in_len, int64_t* out, size_t cap,
                      size_t* total, size_t* consumed);

@@ -18,10 +18,11 @@ import numpy as _np
 from . import _native
 from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
                       ENC_DELTA_BINARY_PACKED, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
-                      HIP_ERROR, NO_DEVICE, OK, PAST_END, PageDesc, PageResult, PqdError, check, lib)
+                      HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY, VIEW_INVALID,
+                      BinaryPageDesc, DictInfo, PageDesc, PageResult, PqdError, check, lib)
 
 __all__ = ["ParquetReadRouter", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
-           "DictionaryValuesReader", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader",
+           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
 
@@ -295,18 +296,90 @@ class ZeroIntegerValuesReader(ValuesReader):
         pass
 
 
+class PlainBinaryDictionary:
+    """PlainValuesDictionary.PlainBinaryDictionary (PlainValuesDictionary.java:59-135): the entries of
+    a PLAIN BYTE_ARRAY dictionary page ([length LE32][bytes]...), or ``length`` bytes each when
+    ``length`` is given (FIXED_LEN_BYTE_ARRAY; INT96 = 12, Encoding.java:97-103).  The page is parsed by
+    ``pqd_binary_dict_views`` and kept on the device by a ``pqd_dict`` handle."""
+
+    def __init__(self, dictionaryPageBytes, dictionarySize, length=None):
+        if length is not None and length <= 0:
+            raise IllegalArgumentException("Invalid byte array length: %s" % length)
+        self._page = _np.ascontiguousarray(_np.frombuffer(bytes(dictionaryPageBytes), _np.uint8))
+        self._n = dictionarySize
+        self._views = _np.zeros(max(dictionarySize, 1), _np.uint64)
+        st = lib.pqd_binary_dict_views(_ptr(self._page), self._page.size, dictionarySize, length or 0,
+                                       self._views.ctypes.data_as(_C.c_void_p))
+        if st == DECODE:
+            raise IndexError("dictionary entry length outside the page")  # IndexOutOfBoundsException
+        _raise_for(st, "PlainBinaryDictionary")
+        self._views = self._views[:dictionarySize]
+        kind = TYPE_BYTE_ARRAY if length is None else TYPE_FIXED_LEN_BYTE_ARRAY
+        self._handle = _C.c_void_p()
+        check(lib.pqd_dict_create(kind, length or 0, _ptr(self._page), self._page.size, dictionarySize,
+                                  _C.byref(self._handle)), "pqd_dict_create")
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            lib.pqd_dict_destroy(h)
+
+    def getMaxId(self):
+        return self._n - 1
+
+    def decodeToBinary(self, id):
+        if not 0 <= id < self._n:
+            raise IndexError(id)  # ArrayIndexOutOfBoundsException
+        v = int(self._views[id])
+        if v == VIEW_INVALID:
+            raise IndexError("dictionary entry outside the page")
+        off, ln = v & 0xFFFFFFFF, v >> 32
+        return self._page[off:off + ln].tobytes()
+
+    def max_length(self):
+        ok = self._views[self._views != _np.uint64(VIEW_INVALID)]
+        return int((ok >> _np.uint64(32)).max()) if ok.size else 0
+
+
 class DictionaryValuesReader(ValuesReader):
-    """DictionaryValuesReader.java:35-128; ``dictionary`` is the decoded PLAIN dictionary page as a
-    numpy array of int32/int64/float32/float64 (PlainValuesDictionary.java:148-157,232-241)."""
+    """DictionaryValuesReader.java:35-128; ``dictionary`` is the decoded PLAIN dictionary page: a
+    numpy array of int32/int64/float32/float64 (PlainValuesDictionary.java:148-157,232-241), or a
+    ``PlainBinaryDictionary`` (then ``readBytes`` is the accessor, :76-83)."""
     _encoding = ENC_RLE_DICTIONARY
 
     def __init__(self, dictionary):
-        self._dict = _np.ascontiguousarray(dictionary)
-        self._dtype = self._dict.dtype
+        self._binary = dictionary if isinstance(dictionary, PlainBinaryDictionary) else None
+        self._dict = None if self._binary else _np.ascontiguousarray(dictionary)
+        self._dtype = _np.uint64 if self._binary else self._dict.dtype
         super().__init__()
 
     def _dict_array(self):
         return self._dict
+
+    def initFromPage(self, valueCount, stream):
+        if self._binary is None:
+            return super().initFromPage(valueCount, stream)
+        data = _np.ascontiguousarray(stream._peek_all())
+        cap = max(valueCount * self._binary.max_length(), 1)
+        self._offsets = _np.zeros(valueCount + 1, _np.int32)
+        self._bytes = _np.zeros(cap, _np.uint8)
+        r = PageResult()
+        check(lib.pqd_decode_binary_page(self._binary._handle, _ptr(data), data.size, valueCount,
+                                         _ptr(self._offsets), _ptr(self._bytes), cap, _C.byref(r)),
+              "pqd_decode_binary_page")
+        self._status = r.status
+        self._values = _np.arange(r.values_written)  # positions; the bytes are cut out in readBytes
+        self._i = 0
+        stream.skipFully(stream.available())
+
+    def readBytes(self):
+        i = int(self._next())
+        return self._bytes[self._offsets[i]:self._offsets[i + 1]].tobytes()
+
+    def offsets_and_bytes(self):
+        """Bulk access (not in the reference interface): offsets[n+1] and the value bytes."""
+        n = len(self._values)
+        return self._offsets[:n + 1], self._bytes[:self._offsets[n]]
 
     def _fail_at_end(self):
         if self._status == OK and len(self._values) == 0:

@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("PQD_LIB_PATH") or os.path.join(_HERE, "lib", "libpqde
 OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
 F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
+TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 1, 2, 3, 4, 5, 6, 7
+VIEW_INVALID = 0xFFFFFFFFFFFFFFFF
 
 
 class PageDesc(C.Structure):
@@ -31,7 +33,18 @@ class PageResult(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
-assert C.sizeof(PageDesc) == 40 and C.sizeof(PageResult) == 16
+class DictInfo(C.Structure):
+    _fields_ = [("entries", C.c_void_p), ("bytes", C.c_void_p), ("n_entries", C.c_uint32),
+                ("elem_size", C.c_uint32), ("bytes_len", C.c_uint32), ("physical_type", C.c_uint32)]
+
+
+class BinaryPageDesc(C.Structure):
+    _fields_ = [("views", C.c_void_p), ("dict_bytes", C.c_void_p), ("offsets", C.c_void_p), ("bytes", C.c_void_p),
+                ("num_values", C.c_uint32), ("dict_bytes_len", C.c_uint32), ("bytes_capacity", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+assert C.sizeof(PageDesc) == 40 and C.sizeof(PageResult) == 16 and C.sizeof(BinaryPageDesc) == 48
 
 EXPORTS = {
     "pqd_version": ([], C.c_int),
@@ -63,6 +76,13 @@ EXPORTS = {
     "pqd_decode_pages_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "pqd_decode_pages": ([C.POINTER(PageDesc), C.POINTER(PageResult), C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_page": ([C.POINTER(PageDesc), C.POINTER(PageResult)], C.c_int),
+    "pqd_binary_dict_views": ([C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
+    "pqd_dict_create": ([C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)], C.c_int),
+    "pqd_dict_get": ([C.c_void_p, C.POINTER(DictInfo)], C.c_int),
+    "pqd_dict_destroy": ([C.c_void_p], C.c_int),
+    "pqd_binary_materialize_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_decode_binary_page": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.POINTER(PageResult)], C.c_int),
 }
 
 if not os.path.exists(LIB_PATH):

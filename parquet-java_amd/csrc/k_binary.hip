@@ -1,0 +1,215 @@
+// BINARY (BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY / INT96) dictionary values gathered into one buffer.
+//
+// The reference hands out Binary objects that are views into the dictionary page
+// (parquet-column/.../values/dictionary/PlainValuesDictionary.java:96-113, decodeToBinary :118) and the
+// caller copies their bytes (DictionaryValuesReader.readBytes, DictionaryValuesReader.java:76-83, then
+// Binary.getBytes / writeTo).  Here a page's values arrive as 8-byte views {offset, length} (the
+// dictionary gather with a dictionary of views), and this kernel does the read loop for a whole page:
+// offsets[i] = where value i starts, bytes = the values back to back.
+//
+// One 256-thread workgroup per page, tiles of 2048 values.  A lane owns eight consecutive values: it
+// loads their views, a workgroup prefix sum over the lengths gives every value its place, the value
+// bytes are fetched with one unaligned 16-byte load each (all eight in flight together), OR-ed into a
+// zeroed LDS window at their byte position, and the window goes out in aligned 16-byte stores.
+// Values longer than 16 bytes, values at the very end of the dictionary and values that straddle a
+// window edge are copied byte by byte.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+
+namespace pqd {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_VPL = 8;  // values per lane and tile
+constexpr uint32_t BN_TILE = BN_THREADS * BN_VPL;
+constexpr uint32_t BN_WIN = 24 * 1024;  // output bytes staged per window
+constexpr uint32_t BN_NONE = 0xFFFFFFFFu;
+
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint64_t u64_a8 __attribute__((aligned(8)));
+
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
+  const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ORs `count` (1..16) bytes held in `v` (little-endian, bytes past count are ignored) into the
+// zeroed window at byte position `dst`.
+__device__ __forceinline__ void or_bytes(uint32_t* win, uint32_t dst, u32x4 v, uint32_t count) {
+  v = keep_leading_bytes(v, (long)count);
+  const uint32_t sh = (dst & 3u) * 8u, dw = dst >> 2;
+  const uint32_t nd = ((dst & 3u) + count + 3u) >> 2;  // dwords touched: 1..5
+  const uint32_t d[5] = {v.x, v.y, v.z, v.w, 0u};
+  uint32_t prev = 0u;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const uint32_t piece = (uint32_t)(((((uint64_t)d[k]) << 32) | prev) >> (32u - sh));
+    if ((uint32_t)k < nd) atomicOr(&win[dw + k], piece);
+    prev = d[k];
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_binary_pages(const pqd_binary_page_desc* __restrict__ descs,
+                                                             pqd_page_result* results, uint32_t n_pages) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[(BN_WIN + 32) / 4];
+  __shared__ uint64_t wave_total[BN_THREADS / 64];
+  __shared__ uint32_t s_stop, s_stop_status;
+  __shared__ uint64_t s_stop_bytes;
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const pqd_binary_page_desc d = descs[page];
+  const uint32_t n = d.num_values;
+  const uint64_t cap = d.bytes_capacity > 0x7fffffffu ? 0x7fffffffull : d.bytes_capacity;  // int32 offsets
+  const uint8_t* __restrict__ dict = d.dict_bytes;
+  const uint64_t dict_len = d.dict_bytes_len;
+  uint32_t running = 0;  // bytes written so far
+  uint32_t status = PQD_OK, written = n;
+  bool stopped = false;
+
+  for (uint32_t t0 = 0; t0 < n && !stopped; t0 += BN_TILE) {
+    if (tid == 0) s_stop = BN_NONE;
+    const uint32_t g0 = t0 + tid * BN_VPL;
+    uint32_t off[BN_VPL], len[BN_VPL];
+    bool bad[BN_VPL];
+#pragma unroll
+    for (int j = 0; j < BN_VPL; ++j) {
+      const uint64_t v = g0 + j < n ? *(const u64_a8*)(d.views + g0 + j) : 0ull;
+      off[j] = (uint32_t)v;
+      len[j] = (uint32_t)(v >> 32);
+      bad[j] = len[j] == 0xFFFFFFFFu || (uint64_t)off[j] + len[j] > dict_len;
+      if (bad[j]) len[j] = 0;
+    }
+    // the value bytes: one 16-byte load per value where that is enough and stays inside the
+    // dictionary; every lane loads (the others from 16 bytes that are always there: the page's own
+    // result record), so that the eight loads are in flight together
+    u32x4 data[BN_VPL];
+    bool fast[BN_VPL];
+#pragma unroll
+    for (int j = 0; j < BN_VPL; ++j) {
+      fast[j] = len[j] != 0 && len[j] <= 16u && (uint64_t)off[j] + 16u <= dict_len;
+      const uint8_t* src = fast[j] ? dict + off[j] : (const uint8_t*)(results + page);
+      const u32x4_a1 raw = *(const u32x4_a1*)src;
+      data[j] = u32x4{raw.x, raw.y, raw.z, raw.w};
+    }
+    // prefix sums of the lengths: within the lane, the wave, the workgroup
+    uint64_t pre[BN_VPL], lane_total = 0;
+#pragma unroll
+    for (int j = 0; j < BN_VPL; ++j) {
+      pre[j] = lane_total;
+      lane_total += len[j];
+    }
+    uint64_t inc = lane_total;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint64_t o = shfl_up64(inc, s);
+      if (lane >= (uint32_t)s) inc += o;
+    }
+    if (lane == 63) wave_total[wave] = inc;
+    __syncthreads();
+    uint64_t lane_base = inc - lane_total, tile_total = 0;
+#pragma unroll
+    for (int k = 0; k < BN_THREADS / 64; ++k) {
+      const uint64_t wt = wave_total[k];
+      if ((uint32_t)k < wave) lane_base += wt;
+      tile_total += wt;
+    }
+    // the first value that cannot be delivered: a broken view, or bytes beyond the capacity
+    uint32_t my_stop = BN_NONE;
+#pragma unroll
+    for (int j = BN_VPL - 1; j >= 0; --j) {
+      const bool over = (uint64_t)running + lane_base + pre[j] + len[j] > cap;
+      if (g0 + j < n && (bad[j] || over)) my_stop = tid * BN_VPL + j;
+    }
+    if (my_stop != BN_NONE) atomicMin(&s_stop, my_stop);
+    __syncthreads();
+    const uint32_t stop = s_stop;  // tile-relative index, BN_NONE if the whole tile is fine
+    if (stop != BN_NONE && stop / BN_VPL == tid) {
+#pragma unroll
+      for (int j = 0; j < BN_VPL; ++j)
+        if ((uint32_t)j == stop % BN_VPL) {
+          s_stop_bytes = lane_base + pre[j];
+          s_stop_status = bad[j] ? PQD_DECODE : PQD_BAD_ARG;
+        }
+    }
+    // where the values start (the value that stops the page gets the end of the one before it)
+    {
+      const uint32_t first = running + (uint32_t)lane_base;
+      if (g0 + BN_VPL <= n && (stop == BN_NONE || tid * BN_VPL + BN_VPL - 1 <= stop)) {
+        const u32x4_a4 lo = {first + (uint32_t)pre[0], first + (uint32_t)pre[1], first + (uint32_t)pre[2],
+                             first + (uint32_t)pre[3]};
+        const u32x4_a4 hi = {first + (uint32_t)pre[4], first + (uint32_t)pre[5], first + (uint32_t)pre[6],
+                             first + (uint32_t)pre[7]};
+        *(u32x4_a4*)(d.offsets + g0) = lo;
+        *(u32x4_a4*)(d.offsets + g0 + 4) = hi;
+      } else {
+#pragma unroll
+        for (int j = 0; j < BN_VPL; ++j)
+          if (g0 + j < n && tid * BN_VPL + j <= stop) d.offsets[g0 + j] = (int32_t)(first + (uint32_t)pre[j]);
+      }
+    }
+    __syncthreads();
+    uint32_t tile_bytes = (uint32_t)tile_total;  // below 2^31 when nothing stops the page
+    if (stop != BN_NONE) {
+      tile_bytes = (uint32_t)s_stop_bytes;
+      status = s_stop_status;
+      written = t0 + stop;
+      stopped = true;
+    }
+    // the bytes, one LDS window after the other
+    for (uint32_t wb = 0; wb < tile_bytes; wb += BN_WIN) {
+      const uint32_t wlen = tile_bytes - wb < BN_WIN ? tile_bytes - wb : BN_WIN;
+      uint8_t* gdst = d.bytes + running + wb;
+      const uint32_t s = (uint32_t)((uintptr_t)gdst & 15u);
+      const uint32_t pieces = (s + wlen + 15u) >> 4;
+      for (uint32_t i = tid; i < pieces; i += BN_THREADS) ((u32x4*)win)[i] = u32x4{0u, 0u, 0u, 0u};
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BN_VPL; ++j) {
+        if (tid * BN_VPL + j >= stop || len[j] == 0) continue;
+        const uint32_t b0 = (uint32_t)(lane_base + pre[j]), b1 = b0 + len[j];
+        if (b1 <= wb || b0 >= wb + wlen) continue;
+        if (fast[j] && b0 >= wb && b1 <= wb + wlen) {
+          or_bytes(win, s + (b0 - wb), data[j], len[j]);
+        } else {
+          const uint32_t lo = b0 > wb ? b0 : wb, hi = b1 < wb + wlen ? b1 : wb + wlen;
+          for (uint32_t b = lo; b < hi; ++b) {
+            const uint32_t dst = s + (b - wb);
+            atomicOr(&win[dst >> 2], (uint32_t)dict[(uint64_t)off[j] + (b - b0)] << ((dst & 3u) * 8u));
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t end = s + wlen;
+      for (uint32_t i = tid; i < pieces; i += BN_THREADS) {
+        const u32x4 v = ((const u32x4*)win)[i];
+        const uint32_t p0 = i * 16u;
+        if (p0 >= s && p0 + 16u <= end) {
+          *(u32x4*)(gdst - s + p0) = v;
+        } else {  // the first and the last piece of a window: only the bytes that belong to it
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (uint32_t k = 0; k < 16u; ++k)
+            if (p0 + k >= s && p0 + k < end) gdst[(long)(p0 + k) - (long)s] = (uint8_t)(w4[k >> 2] >> ((k & 3u) * 8u));
+        }
+      }
+      __syncthreads();
+    }
+    running += tile_bytes;
+  }
+  if (tid == 0) {
+    if (!stopped) d.offsets[n] = (int32_t)running;
+    results[page].status = (int32_t)status;
+    results[page].values_written = written;
+    results[page].bytes_consumed = running;
+    results[page].reserved = 0;
+  }
+}
+
+hipError_t launch_binary_pages(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
+                               hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_binary_pages, dim3(n_pages), dim3(BN_THREADS), 0, stream, descs, results, n_pages);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -524,4 +524,182 @@ int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result) {
   return PQD_OK;
 }
 
+/* ---- dictionaries --------------------------------------------------------------------------- */
+
+int pqd_binary_dict_views(const uint8_t* page, size_t page_len, uint32_t n_entries, int fixed_length,
+                          uint64_t* views) {
+  if (fixed_length < 0) return fail(PQD_BAD_ARG, "Invalid byte array length");
+  if ((page_len && !page) || (n_entries && !views)) return fail(PQD_BAD_ARG, "null dictionary page / views");
+  int64_t offset = 0;  // a Java int in the reference: a negative length walks backwards
+  for (uint32_t i = 0; i < n_entries; ++i) {
+    int32_t len = fixed_length;
+    if (fixed_length == 0) {
+      if (offset < 0 || (uint64_t)offset + 4 > page_len) return fail(PQD_DECODE, "dictionary entry length outside the page");
+      uint32_t raw;
+      memcpy(&raw, page + offset, 4);
+      len = (int32_t)raw;
+      offset += 4;
+    }
+    if (len < 0 || offset < 0 || (uint64_t)offset + (uint64_t)len > page_len || offset > 0x7fffffff)
+      views[i] = PQD_VIEW_INVALID;
+    else
+      views[i] = ((uint64_t)(uint32_t)len << 32) | (uint32_t)offset;
+    offset += len;
+    if (offset > 0x7fffffffLL || offset < -0x80000000LL) return fail(PQD_DECODE, "dictionary page offsets overflow");
+  }
+  return PQD_OK;
+}
+
+}  // extern "C"
+
+struct pqd_dict {
+  void* entries = nullptr;
+  uint8_t* bytes = nullptr;
+  uint32_t n_entries = 0, elem_size = 0, bytes_len = 0, physical_type = 0;
+  int device = 0;
+};
+
+extern "C" {
+
+int pqd_dict_create(int physical_type, int type_length, const uint8_t* page, size_t page_len, uint32_t n_entries,
+                    pqd_dict** dict) {
+  if (!dict) return fail(PQD_BAD_ARG, "null dictionary handle");
+  *dict = nullptr;
+  if (page_len && !page) return fail(PQD_BAD_ARG, "null dictionary page");
+  if (page_len > 0x7fffffffu) return fail(PQD_BAD_ARG, "dictionary page larger than a Java array");
+  int st = check_device_available();
+  if (st) return st;
+  pqd_dict d;
+  d.physical_type = (uint32_t)physical_type;
+  d.n_entries = n_entries;
+  PQD_HIP(hipGetDevice(&d.device));
+  std::vector<uint64_t> views;
+  const void* host_entries = page;
+  size_t entry_bytes = 0;
+  switch (physical_type) {
+    case PQD_TYPE_INT32:
+    case PQD_TYPE_FLOAT:
+      d.elem_size = 4;
+      break;
+    case PQD_TYPE_INT64:
+    case PQD_TYPE_DOUBLE:
+      d.elem_size = 8;
+      break;
+    case PQD_TYPE_BYTE_ARRAY:
+    case PQD_TYPE_FIXED_LEN_BYTE_ARRAY:
+    case PQD_TYPE_INT96: {
+      int fixed = physical_type == PQD_TYPE_BYTE_ARRAY ? 0 : physical_type == PQD_TYPE_INT96 ? 12 : type_length;
+      if (physical_type == PQD_TYPE_FIXED_LEN_BYTE_ARRAY && fixed <= 0) return fail(PQD_BAD_ARG, "Invalid byte array length");
+      views.resize(n_entries ? n_entries : 1);
+      if ((st = pqd_binary_dict_views(page, page_len, n_entries, fixed, views.data()))) return st;
+      d.elem_size = 8;
+      host_entries = views.data();
+      break;
+    }
+    default:
+      return fail(PQD_BAD_ARG, "no dictionary for this physical type");
+  }
+  entry_bytes = (size_t)n_entries * d.elem_size;
+  if (host_entries == page && entry_bytes > page_len)
+    return fail(PQD_DECODE, "dictionary page holds fewer values than its dictionarySize");
+  // 16 spare bytes behind both arrays: the kernels read whole 16-byte pieces
+  PQD_HIP(hipMalloc(&d.entries, entry_bytes + 16));
+  hipError_t e = hipSuccess;
+  if (entry_bytes) e = hipMemcpy(d.entries, host_entries, entry_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess && host_entries != page) {
+    d.bytes_len = (uint32_t)page_len;
+    e = hipMalloc((void**)&d.bytes, page_len + 16);
+    if (e == hipSuccess && page_len) e = hipMemcpy(d.bytes, page, page_len, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(d.entries);
+    if (d.bytes) (void)hipFree(d.bytes);
+    return fail(PQD_HIP_ERROR, "dictionary upload", e);
+  }
+  *dict = new pqd_dict(d);
+  return PQD_OK;
+}
+
+int pqd_dict_get(const pqd_dict* dict, pqd_dict_info* info) {
+  if (!dict || !info) return fail(PQD_BAD_ARG, "null dictionary handle / info");
+  info->entries = dict->entries;
+  info->bytes = dict->bytes;
+  info->n_entries = dict->n_entries;
+  info->elem_size = dict->elem_size;
+  info->bytes_len = dict->bytes_len;
+  info->physical_type = dict->physical_type;
+  return PQD_OK;
+}
+
+int pqd_dict_destroy(pqd_dict* dict) {
+  if (!dict) return PQD_OK;
+  hipError_t e1 = hipFree(dict->entries), e2 = dict->bytes ? hipFree(dict->bytes) : hipSuccess;
+  delete dict;
+  if (e1 != hipSuccess) return fail(PQD_HIP_ERROR, "hipFree(dictionary entries)", e1);
+  if (e2 != hipSuccess) return fail(PQD_HIP_ERROR, "hipFree(dictionary bytes)", e2);
+  return PQD_OK;
+}
+
+int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
+                               void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  PQD_HIP(pqd::launch_binary_pages(descs, results, n_pages, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
+                           int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result) {
+  if (!dict || !result) return fail(PQD_BAD_ARG, "null dictionary handle / result");
+  if (!dict->bytes) return fail(PQD_BAD_ARG, "not a BINARY dictionary");
+  if ((page_len && !page) || !offsets || (bytes_capacity && !bytes)) return fail(PQD_BAD_ARG, "null page / output");
+  int st = check_device_available();
+  if (st) return st;
+  HostCtx& c = g_ctx;
+  // device staging: page | views (in `out`) | offsets + bytes (in `dict`) | descriptors + results
+  const size_t views_bytes = (size_t)num_values * 8, offs_bytes = ((size_t)num_values + 1) * 4;
+  const size_t offs_padded = (offs_bytes + 15) & ~(size_t)15;
+  if ((st = c.in.ensure((size_t)page_len + 16))) return st;
+  if ((st = c.out.ensure(views_bytes + 16))) return st;
+  if ((st = c.dict.ensure(offs_padded + bytes_capacity + 16))) return st;
+  if ((st = c.descs.ensure(sizeof(pqd_page_desc) + sizeof(pqd_binary_page_desc)))) return st;
+  if ((st = c.results.ensure(2 * sizeof(pqd_page_result)))) return st;
+  if (page_len) PQD_HIP(hipMemcpyAsync(c.in.p, page, page_len, hipMemcpyHostToDevice, nullptr));
+  pqd_page_desc d{};
+  d.data = (const uint8_t*)c.in.p;
+  d.out = c.out.p;
+  d.dict = dict->entries;
+  d.data_len = page_len;
+  d.num_values = num_values;
+  d.dict_len = dict->n_entries;
+  d.encoding = PQD_ENC_RLE_DICTIONARY;
+  d.elem_size = 8;
+  pqd_page_result ids_result{};
+  if ((st = pqd_decode_pages(&d, &ids_result, 1, nullptr))) return st;
+  pqd_binary_page_desc b{};
+  b.views = (const uint64_t*)c.out.p;
+  b.dict_bytes = dict->bytes;
+  b.offsets = (int32_t*)c.dict.p;
+  b.bytes = (uint8_t*)c.dict.p + offs_padded;
+  b.num_values = ids_result.values_written;  // the values the read loop gets before it fails
+  b.dict_bytes_len = dict->bytes_len;
+  b.bytes_capacity = bytes_capacity;
+  pqd_binary_page_desc* d_b = (pqd_binary_page_desc*)((uint8_t*)c.descs.p + sizeof(pqd_page_desc));
+  pqd_page_result* d_r = (pqd_page_result*)c.results.p + 1;
+  PQD_HIP(hipMemcpyAsync(d_b, &b, sizeof b, hipMemcpyHostToDevice, nullptr));
+  if ((st = pqd_binary_materialize_dev(d_b, d_r, 1, nullptr))) return st;
+  pqd_page_result bin_result{};
+  PQD_HIP(hipMemcpyAsync(&bin_result, d_r, sizeof bin_result, hipMemcpyDeviceToHost, nullptr));
+  PQD_HIP(hipStreamSynchronize(nullptr));
+  PQD_HIP(hipMemcpyAsync(offsets, b.offsets, ((size_t)bin_result.values_written + 1) * 4, hipMemcpyDeviceToHost, nullptr));
+  if (bin_result.bytes_consumed)
+    PQD_HIP(hipMemcpyAsync(bytes, b.bytes, bin_result.bytes_consumed, hipMemcpyDeviceToHost, nullptr));
+  PQD_HIP(hipStreamSynchronize(nullptr));
+  result->status = bin_result.status != PQD_OK ? bin_result.status : ids_result.status;
+  result->values_written = bin_result.values_written;
+  result->bytes_consumed = ids_result.bytes_consumed;
+  result->reserved = bin_result.bytes_consumed;  // bytes written to `bytes`
+  return PQD_OK;
+}
+
 }  // extern "C"

@@ -33,5 +33,8 @@ hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results
                             hipStream_t stream);
 hipError_t launch_bitpacked_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                                   hipStream_t stream);
+// BINARY values gathered from their views into offsets + bytes, one workgroup per page
+hipError_t launch_binary_pages(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
+                               hipStream_t stream);
 
 }  // namespace pqd

@@ -165,6 +165,7 @@ def main():
                     pos = body + size
                     if h[1] == 2:  # DICTIONARY_PAGE: PLAIN BYTE_ARRAY entries [len LE32][bytes]
                         n = h[7][1]
+                        dictionary_page = bytes(payload)
                         dictionary, q = [], 0
                         for _ in range(n):
                             ln = struct.unpack_from("<i", payload, q)[0]
@@ -206,7 +207,8 @@ def main():
                         assert max(ids) < len(dictionary)
                         fixtures.append(dict(base, kind="dictionary_ids", encoding=enc, bit_width=w,
                                              data=bytes(sect).hex(), expected=ids, num_values=n_present,
-                                             dictionary=[d.decode("latin-1") for d in dictionary]))
+                                             dictionary=[d.decode("latin-1") for d in dictionary],
+                                             dictionary_page=dictionary_page.hex()))
                         decoded_strings += [dictionary[i] for i in ids]
                     page_no += 1
                 # ---- cross-checks against pyarrow's reading of the same chunk

@@ -93,3 +93,52 @@ def unpack_dev(w, packed, n, long=False, offset=0):
     torch.cuda.synchronize()
     out = d_out.cpu().numpy()
     return st, out[:n], out[n:]
+
+
+def materialize_binary(cases, fill=0xA5):
+    """One pqd_binary_materialize_dev launch.  cases: (views uint64[n], dict_bytes uint8[], capacity).
+    Outputs sit at odd addresses between guard bytes.  Returns per case
+    (status, values_written, bytes_written, offsets int32[n+1], bytes uint8[capacity], [guards])."""
+    dicts, blobs = {}, []
+    o_pos, b_pos, v_pos = 0, 0, 0
+    lay = []
+    for views, dict_bytes, cap in cases:
+        n = len(views)
+        o_pos = (o_pos + 3) & ~3
+        lay.append((v_pos, o_pos + 4, b_pos + 3))
+        v_pos += n * 8
+        o_pos += 4 + (n + 1) * 4 + 12
+        b_pos += 3 + cap + 13
+    all_views = np.concatenate([np.ascontiguousarray(c[0], np.uint64) for c in cases] + [np.zeros(1, np.uint64)])
+    d_views = to_dev(all_views)
+    d_offs = torch.full((o_pos + 16,), fill, dtype=torch.uint8, device=dev())
+    d_bytes = torch.full((b_pos + 16,), fill, dtype=torch.uint8, device=dev())
+    descs = (pq.BinaryPageDesc * len(cases))()
+    for i, ((views, dict_bytes, cap), (vp, op, bp)) in enumerate(zip(cases, lay)):
+        key = id(dict_bytes)
+        if key not in dicts:
+            dicts[key] = to_dev(dict_bytes) if len(dict_bytes) else torch.zeros(16, dtype=torch.uint8, device=dev())
+        descs[i].views = d_views.data_ptr() + vp
+        descs[i].dict_bytes = dicts[key].data_ptr()
+        descs[i].offsets = d_offs.data_ptr() + op
+        descs[i].bytes = d_bytes.data_ptr() + bp
+        descs[i].num_values = len(views)
+        descs[i].dict_bytes_len = len(dict_bytes)
+        descs[i].bytes_capacity = cap
+    d_descs = to_dev(np.frombuffer(bytes(descs), np.uint8).copy())
+    d_res = torch.zeros(len(cases) * 16, dtype=torch.uint8, device=dev())
+    st = pq.lib.pqd_binary_materialize_dev(d_descs.data_ptr(), d_res.data_ptr(), len(cases),
+                                           torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    status, written, consumed = pq.results_from_numpy(d_res.cpu().numpy())
+    offs, data = d_offs.cpu().numpy(), d_bytes.cpu().numpy()
+    res = []
+    for i, ((views, dict_bytes, cap), (vp, op, bp)) in enumerate(zip(cases, lay)):
+        n = len(views)
+        w = int(written[i])
+        o = offs[op:op + (n + 1) * 4].view(np.int32)
+        guards = [offs[op - 4:op], offs[op + (w + 1) * 4:op + (n + 1) * 4 + 12] if status[i] else offs[op + (n + 1) * 4:op + (n + 1) * 4 + 12],
+                  data[bp - 3:bp], data[bp + cap:bp + cap + 13], data[bp + int(consumed[i]):bp + cap]]
+        res.append((int(status[i]), w, int(consumed[i]), o.copy(), data[bp:bp + cap].copy(), guards))
+    return res
