@@ -245,6 +245,73 @@ def main():
         extras["binary_column_as_dictionary_ids"] = {"ms": round(ms, 4), "values_per_s": round(args.pages * PAGE_VALUES / ms * 1e3, 1),
                                                      "verified": ok}
 
+        # ... and the same column materialised: offsets[n+1] + value bytes per page.  Dictionary entries of
+        # 4..12 bytes (a 768 KiB dictionary page); ids -> 8-byte views (the INT64 gather with the
+        # dictionary's views as entries) -> k_binary_pages
+        rng = np.random.default_rng(77)
+        lens = rng.integers(4, 13, DICT_ENTRIES)
+        body = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+        page = np.zeros(int(lens.sum()) + 4 * DICT_ENTRIES, np.uint8)
+        starts = np.cumsum(lens + 4) - lens
+        for k in range(4):
+            page[starts - 4 + k] = (lens >> (8 * k)) & 0xFF
+        dst = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(body.size)
+        page[dst] = body
+        handle = C.c_void_p()
+        pq.check(pq.lib.pqd_dict_create(pq.TYPE_BYTE_ARRAY, 0, page.ctypes.data_as(C.c_void_p), page.size, DICT_ENTRIES,
+                                        C.byref(handle)))
+        info = pq.DictInfo()
+        pq.check(pq.lib.pqd_dict_get(handle, C.byref(info)))
+        c = cols[1]
+        views_out = c["out"]  # 8 bytes per value
+        v_pages = [dict(data=c["blob"].data_ptr() + i * c["page_len"], out=views_out.data_ptr() + i * PAGE_VALUES * 8,
+                        dict=info.entries, data_len=c["page_len"], num_values=PAGE_VALUES, dict_len=DICT_ENTRIES,
+                        encoding=pq.ENC_RLE_DICTIONARY, elem_size=8) for i in range(args.pages)]
+        v_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(v_pages))).to(device)
+        v_res = torch.zeros(args.pages * 16, dtype=torch.uint8, device=device)
+        cap = PAGE_VALUES * 12
+        b_offsets = torch.zeros((args.pages, PAGE_VALUES + 1), dtype=torch.int32, device=device)
+        b_bytes = torch.zeros((args.pages, cap), dtype=torch.uint8, device=device)
+        bd = (pq.BinaryPageDesc * args.pages)()
+        for i in range(args.pages):
+            bd[i].views = views_out.data_ptr() + i * PAGE_VALUES * 8
+            bd[i].dict_bytes = info.bytes
+            bd[i].offsets = b_offsets.data_ptr() + i * (PAGE_VALUES + 1) * 4
+            bd[i].bytes = b_bytes.data_ptr() + i * cap
+            bd[i].num_values = PAGE_VALUES
+            bd[i].dict_bytes_len = info.bytes_len
+            bd[i].bytes_capacity = cap
+        b_descs = torch.from_numpy(np.frombuffer(bytes(bd), np.uint8).copy()).to(device)
+        b_res = torch.zeros(args.pages * 16, dtype=torch.uint8, device=device)
+        ms_views = timed(lambda: pq.decode_pages_dev(v_descs.data_ptr(), v_res.data_ptr(), args.pages,
+                                                     pq.ENC_RLE_DICTIONARY, 8, stream))
+        ms_bytes = timed(lambda: pq.check(pq.lib.pqd_binary_materialize_dev(b_descs.data_ptr(), b_res.data_ptr(),
+                                                                            args.pages, stream)))
+        st_b, wr_b, nb_b = pq.results_from_numpy(b_res.cpu().numpy())
+        ok = bool((st_b == 0).all() and (wr_b == PAGE_VALUES).all())
+        chk = min(args.pages, 64)  # the first pages, value bytes rebuilt with torch
+        t_lens = torch.from_numpy(lens).to(device)
+        t_starts = torch.from_numpy(starts).to(device)
+        t_page = torch.from_numpy(page).to(device)
+        ids_chk = c["ids"][:chk].long()
+        l_chk = t_lens[ids_chk]
+        exp_off = torch.zeros((chk, PAGE_VALUES + 1), dtype=torch.int64, device=device)
+        exp_off[:, 1:] = torch.cumsum(l_chk, 1)
+        ok = ok and bool(torch.equal(exp_off.to(torch.int32), b_offsets[:chk]))
+        for i in range(chk):
+            src = torch.repeat_interleave(t_starts[ids_chk[i]] - exp_off[i, :-1], l_chk[i]) + \
+                torch.arange(int(exp_off[i, -1]), device=device)
+            ok = ok and bool(torch.equal(t_page[src], b_bytes[i, :int(exp_off[i, -1])]))
+        total_bytes = int(nb_b.astype(np.int64).sum())
+        alg = args.pages * c["page_len"] + args.pages * (PAGE_VALUES + 1) * 4 + total_bytes
+        extras["binary_column_offsets_and_bytes"] = {
+            "ms_ids_to_views": round(ms_views, 4), "ms_views_to_bytes": round(ms_bytes, 4),
+            "values_per_s": round(args.pages * PAGE_VALUES / (ms_views + ms_bytes) * 1e3, 1),
+            "algorithmic_GBps": round(alg / (ms_views + ms_bytes) / 1e6, 1),
+            "mean_value_bytes": round(total_bytes / (args.pages * PAGE_VALUES), 2), "verified_pages": chk, "verified": ok}
+        pq.lib.pqd_dict_destroy(handle)
+        del b_offsets, b_bytes, t_page
+
     n_vals = args.pages * PAGE_VALUES
     decoded_bytes_step = n_vals * (4 + 8)
     encoded_bytes_col = args.pages * cols[0]["page_len"]
@@ -272,7 +339,7 @@ def main():
             "config": {"workload": "configs[1]: dictionary-encoded INT32 + INT64 columns, 65536-entry dictionaries "
                                    "(id width 16), RLE/bit-packed hybrid ids (504-value runs, uniform random ids), "
                                    f"{args.pages} pages x {PAGE_VALUES} values per column per GPU "
-                                   f"({n_vals / 1e6:.0f} M rows x 2 columns); BINARY column not included",
+                                   f"({n_vals / 1e6:.0f} M rows x 2 columns); the BINARY column is reported under extras",
                        "pages_per_column": args.pages, "page_values": PAGE_VALUES, "dictionary_entries": DICT_ENTRIES,
                        "sharding": "one shard per GPU, no collective"},
             "values_per_s": round(2 * n_vals * world / (elapsed / args.steps), 1),

@@ -211,6 +211,95 @@ class DictionaryValuesReader : public ValuesReader {
   }
 };
 
+// PlainValuesDictionary.PlainBinaryDictionary (.../values/dictionary/PlainValuesDictionary.java:59-135):
+// a PLAIN dictionary page of BYTE_ARRAY entries, or of `length`-byte entries (FIXED_LEN_BYTE_ARRAY;
+// INT96 = 12, Encoding.java:97-103).  The page is walked by pqd_binary_dict_views and kept on the
+// device by a pqd_dict handle.
+class PlainBinaryDictionary {
+ public:
+  PlainBinaryDictionary(const uint8_t* dictionaryPage, size_t pageLength, uint32_t dictionarySize, int length = 0)
+      : page_(dictionaryPage, dictionaryPage + pageLength), views_(dictionarySize ? dictionarySize : 1) {
+    if (length < 0) throw IllegalArgumentException("Invalid byte array length");
+    int st = pqd_binary_dict_views(page_.data(), page_.size(), dictionarySize, length, views_.data());
+    if (st == PQD_DECODE) throw std::out_of_range("dictionary entry length outside the page");  // IndexOutOfBoundsException
+    raise_for(st, "PlainBinaryDictionary");
+    views_.resize(dictionarySize);
+    raise_for(pqd_dict_create(length ? PQD_TYPE_FIXED_LEN_BYTE_ARRAY : PQD_TYPE_BYTE_ARRAY, length, page_.data(),
+                              page_.size(), dictionarySize, &handle_),
+              "pqd_dict_create");
+  }
+  PlainBinaryDictionary(const PlainBinaryDictionary&) = delete;
+  PlainBinaryDictionary& operator=(const PlainBinaryDictionary&) = delete;
+  ~PlainBinaryDictionary() { pqd_dict_destroy(handle_); }
+
+  int getMaxId() const { return (int)views_.size() - 1; }
+  std::string decodeToBinary(int id) const {
+    const uint64_t v = views_.at((size_t)id);  // std::out_of_range = ArrayIndexOutOfBoundsException
+    if (v == PQD_VIEW_INVALID) throw std::out_of_range("dictionary entry outside the page");
+    return std::string((const char*)page_.data() + (uint32_t)v, (size_t)(v >> 32));
+  }
+  uint32_t maxLength() const {
+    uint32_t m = 0;
+    for (uint64_t v : views_)
+      if (v != PQD_VIEW_INVALID && (uint32_t)(v >> 32) > m) m = (uint32_t)(v >> 32);
+    return m;
+  }
+  const pqd_dict* handle() const { return handle_; }
+
+ private:
+  std::vector<uint8_t> page_;
+  std::vector<uint64_t> views_;
+  pqd_dict* handle_ = nullptr;
+};
+
+// DictionaryValuesReader over a PlainBinaryDictionary: readBytes() (DictionaryValuesReader.java:76-83).
+class BinaryDictionaryValuesReader {
+ public:
+  explicit BinaryDictionaryValuesReader(const PlainBinaryDictionary& dictionary) : dict_(dictionary) {}
+  void initFromPage(int valueCount, ByteBufferInputStream& stream) {
+    const uint32_t n = (uint32_t)(valueCount > 0 ? valueCount : 0);
+    const uint64_t cap64 = (uint64_t)n * dict_.maxLength();
+    const uint32_t cap = cap64 > 0x7fffffffu ? 0x7fffffffu : (uint32_t)cap64;
+    offsets_.assign((size_t)n + 1, 0);
+    bytes_.assign(cap ? cap : 1, 0);
+    pqd_page_result r;
+    std::memset(&r, 0, sizeof r);
+    raise_for(pqd_decode_binary_page(dict_.handle(), stream.available() ? stream.current() : nullptr,
+                                     (uint32_t)stream.available(), n, offsets_.data(), bytes_.data(), cap, &r),
+              "pqd_decode_binary_page");
+    status_ = r.status;
+    count_ = r.values_written;
+    next_ = 0;
+    stream.skipFully(stream.available());
+  }
+  std::string readBytes() {
+    const size_t i = index();
+    return std::string((const char*)bytes_.data() + offsets_[i], (size_t)(offsets_[i + 1] - offsets_[i]));
+  }
+  void skip() { index(); }
+  void skip(int n) {
+    for (int i = 0; i < n; ++i) index();
+  }
+  // bulk access (not part of the reference interface): offsets[valuesWritten()+1] and the value bytes
+  const int32_t* offsets() const { return offsets_.data(); }
+  const uint8_t* bytes() const { return bytes_.data(); }
+  size_t valuesWritten() const { return count_; }
+
+ private:
+  size_t index() {
+    if (next_ >= count_) {
+      if (status_ == PQD_OK && count_ == 0) throw ParquetDecodingException("Attempt to read from empty page");
+      raise_for(status_ != PQD_OK ? status_ : PQD_PAST_END);
+    }
+    return next_++;
+  }
+  const PlainBinaryDictionary& dict_;
+  std::vector<int32_t> offsets_;
+  std::vector<uint8_t> bytes_;
+  size_t count_ = 0, next_ = 0;
+  int status_ = PQD_OK;
+};
+
 // readValueDictionaryId() view of a dictionary-encoded page (DictionaryValuesReader.java:66-73).
 class DictionaryIdReader : public ValuesReader {
  public:

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "pqd_readers.hpp"
@@ -128,6 +129,44 @@ int main() {
     DictionaryValuesReader r3(dict.data(), (uint32_t)dict.size(), 8);
     r3.initFromPage(0, in3);
     EXPECT(throws<ParquetDecodingException>([&] { r3.readLong(); }));
+  }
+
+  // PlainBinaryDictionary + readBytes: TestDictionary.testBinaryDictionary-style "a" + i % 50 strings
+  {
+    std::vector<std::string> words(50);
+    std::vector<uint8_t> dpage;
+    for (int i = 0; i < 50; ++i) {
+      words[i] = "a" + std::to_string(i) + std::string((size_t)(i % 7), 'x');
+      uint32_t l = (uint32_t)words[i].size();
+      for (int b = 0; b < 4; ++b) dpage.push_back((uint8_t)(l >> (8 * b)));
+      dpage.insert(dpage.end(), words[i].begin(), words[i].end());
+    }
+    PlainBinaryDictionary dict(dpage.data(), dpage.size(), 50);
+    EXPECT(dict.getMaxId() == 49 && dict.decodeToBinary(13) == words[13]);
+    EXPECT(throws<std::out_of_range>([&] { dict.decodeToBinary(50); }));
+    std::vector<uint32_t> ids(3000);
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)((i * 7) % 50);
+    std::vector<uint8_t> page = {6};
+    for (size_t g = 0; g < ids.size(); g += 504) {
+      size_t n = std::min<size_t>(504, ids.size() - g);
+      size_t groups = (n + 7) / 8;
+      page.push_back((uint8_t)((groups << 1) | 1));
+      std::vector<uint32_t> part(ids.begin() + g, ids.begin() + g + n);
+      part.resize(groups * 8, 0);
+      std::vector<uint8_t> p = pack_lsb(part, 6);
+      page.insert(page.end(), p.begin(), p.end());
+    }
+    ByteBufferInputStream in = ByteBufferInputStream::wrap(page);
+    BinaryDictionaryValuesReader r(dict);
+    r.initFromPage((int)ids.size(), in);
+    bool ok = r.valuesWritten() == ids.size();
+    for (size_t i = 0; i < ids.size(); ++i) ok = ok && r.readBytes() == words[ids[i]];
+    EXPECT(ok);
+    EXPECT(throws<IllegalArgumentException>([&] { r.readBytes(); }));  // "Reading past RLE/BitPacking stream."
+    // fixed-length entries; a length prefix outside the page
+    PlainBinaryDictionary flba(dpage.data(), 48, 12, 4);
+    EXPECT(flba.decodeToBinary(2) == std::string((const char*)dpage.data() + 8, 4));
+    EXPECT(throws<std::out_of_range>([&] { PlainBinaryDictionary cut(dpage.data(), dpage.size() - 9, 50); }));
   }
 
   // ByteStreamSplitValuesReaderTest: floats, element bytes spread over K streams
