@@ -87,6 +87,48 @@ struct ParquetReadRouter {
   }
 };
 
+// BytePacker (parquet-encoding/.../bitpacking/BytePacker.java:40-148) as handed out by
+// Packer.LITTLE_ENDIAN.newBytePacker(width) / newBytePackerVector(width) (Packer.java:92-121): the
+// per-step interface.  Every call is one device call; bulk callers use ParquetReadRouter.
+class BytePacker {
+ public:
+  explicit BytePacker(int bitWidth) : w_(bitWidth) {
+    if (bitWidth < 0 || bitWidth > 32) throw IllegalArgumentException("bitWidth must be in 0..32");
+  }
+  int getBitWidth() const { return w_; }
+  // ByteBitPacking512VectorLE: 32 values per step for widths 1-7 and 9-15, 64 for 8, 16 for 16-32
+  int getUnpackCount() const { return w_ == 0 ? 0 : w_ == 8 ? 64 : w_ < 16 ? 32 : 16; }
+  void unpack8Values(const uint8_t* input, int inPos, int32_t* output, int outPos) const { unpack(8, input, inPos, output, outPos); }
+  void unpack32Values(const uint8_t* input, int inPos, int32_t* output, int outPos) const { unpack(32, input, inPos, output, outPos); }
+  void unpackValuesUsingVector(const uint8_t* input, int inPos, int32_t* output, int outPos) const {
+    unpack(getUnpackCount(), input, inPos, output, outPos);
+  }
+
+ private:
+  void unpack(int n, const uint8_t* input, int inPos, int32_t* output, int outPos) const {
+    if (n == 0) return;
+    raise_for(pqd_unpack_i32(w_, input + inPos, (size_t)n * (size_t)w_ / 8, output + outPos, (size_t)n), "BytePacker.unpack");
+  }
+  int w_;
+};
+
+// BytePackerForLong (parquet-encoding/.../bitpacking/BytePackerForLong.java:72-105), widths 0..64.
+class BytePackerForLong {
+ public:
+  explicit BytePackerForLong(int bitWidth) : w_(bitWidth) {
+    if (bitWidth < 0 || bitWidth > 64) throw IllegalArgumentException("bitWidth must be in 0..64");
+  }
+  int getBitWidth() const { return w_; }
+  void unpack8Values(const uint8_t* input, int inPos, int64_t* output, int outPos) const { unpack(8, input, inPos, output, outPos); }
+  void unpack32Values(const uint8_t* input, int inPos, int64_t* output, int outPos) const { unpack(32, input, inPos, output, outPos); }
+
+ private:
+  void unpack(int n, const uint8_t* input, int inPos, int64_t* output, int outPos) const {
+    raise_for(pqd_unpack_i64(w_, input + inPos, (size_t)n * (size_t)w_ / 8, output + outPos, (size_t)n), "BytePackerForLong.unpack");
+  }
+  int w_;
+};
+
 // ValuesReader (parquet-column/.../values/ValuesReader.java:107-202).
 class ValuesReader {
  public:

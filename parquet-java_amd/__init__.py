@@ -21,7 +21,7 @@ from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM
                       HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY, VIEW_INVALID,
                       BinaryPageDesc, DictInfo, PageDesc, PageResult, PqdError, check, lib)
 
-__all__ = ["ParquetReadRouter", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
+__all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
            "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
@@ -151,6 +151,129 @@ class ParquetReadRouter:
         buf = _np.ascontiguousarray(in_.slice(total))
         st = lib.pqd_unpack_i64(bitWidth, _ptr(buf), buf.size, _ptr(currentBuffer), currentCount)
         _raise_for(st, "ParquetReadRouter.readLongs")
+
+
+# ------------------------------------------------------------------------------- BytePacker / Packer
+class BytePacker:
+    """Per-step unpackers of one bit width: BytePacker.unpack8Values / unpack32Values /
+    unpackValuesUsingVector / getUnpackCount (BytePacker.java:40-148), as generated into
+    ByteBitPackingLE/BE.Packer0..32 (ByteBasedBitPackingGenerator.java:258-308) and implemented by the
+    vector plugin (ByteBitPacking512VectorLE.java:165-3178).  Every call is one device call
+    (``pqd_unpack_i32`` for LSB-first, a BIT_PACKED page for MSB-first): the compatibility path for
+    callers that are written against this interface; bulk callers use ``ParquetReadRouter``."""
+
+    def __init__(self, bitWidth, msb_first=False):
+        if not 0 <= bitWidth <= 32:
+            raise IllegalArgumentException("bitWidth must be in 0..32")
+        self._w, self._msb = bitWidth, msb_first
+
+    def getBitWidth(self):
+        return self._w
+
+    def getUnpackCount(self):
+        # values per unpackValuesUsingVector step (ByteBitPacking512VectorLE: 32 for widths 1-7 and
+        # 9-15, 64 for width 8, 16 for widths 16-32, 0 for width 0)
+        w = self._w
+        return 0 if w == 0 else 64 if w == 8 else 32 if w < 16 else 16
+
+    def _unpack(self, n, input, inPos, output, outPos):
+        if not (isinstance(output, _np.ndarray) and output.dtype == _np.int32 and output.flags.c_contiguous):
+            raise IllegalArgumentException("output must be a contiguous int32 array")
+        if outPos < 0 or outPos + n > output.size:
+            raise IndexError("output too small")  # ArrayIndexOutOfBoundsException
+        nbytes = n * self._w // 8
+        buf = _np.frombuffer(input, _np.uint8) if not isinstance(input, _np.ndarray) else input.view(_np.uint8).reshape(-1)
+        if inPos < 0 or inPos + nbytes > buf.size:
+            raise IndexError("input too short")  # IndexOutOfBoundsException
+        if n == 0 or self._w == 0:
+            output[outPos:outPos + n] = 0 if n else output[outPos:outPos]
+            return
+        src = _np.ascontiguousarray(buf[inPos:inPos + nbytes])
+        dst = output[outPos:outPos + n]
+        if not self._msb:
+            _raise_for(lib.pqd_unpack_i32(self._w, _ptr(src), src.size, _ptr(dst), n), "BytePacker.unpack")
+            return
+        d = PageDesc()
+        d.data, d.data_len, d.out, d.num_values = src.ctypes.data, src.size, dst.ctypes.data, n
+        d.encoding, d.elem_size, d.bit_width = ENC_BIT_PACKED, 4, self._w
+        r = PageResult()
+        check(lib.pqd_decode_page(_C.byref(d), _C.byref(r)), "pqd_decode_page")
+        _raise_for(r.status, "BytePacker.unpack")
+
+    def unpack8Values(self, input, inPos, output, outPos):
+        self._unpack(8, input, inPos, output, outPos)
+
+    def unpack32Values(self, input, inPos, output, outPos):
+        self._unpack(32, input, inPos, output, outPos)
+
+    def unpackValuesUsingVector(self, input, inPos, output, outPos):
+        if self._msb:
+            raise RuntimeError("unpackValuesUsingVector must be implemented by subclass!")  # BytePacker.java:139-147
+        self._unpack(self.getUnpackCount(), input, inPos, output, outPos)
+
+    def pack8Values(self, *a):
+        raise RuntimeError("pack is not part of the decode library")  # the vector plugin throws too (:3229-3232)
+
+    pack32Values = pack8Values
+
+
+class BytePackerForLong:
+    """BytePackerForLong.unpack8Values / unpack32Values (BytePackerForLong.java:72-105), widths 0..64,
+    LSB-first (the delta reader's unpacker)."""
+
+    def __init__(self, bitWidth):
+        if not 0 <= bitWidth <= 64:
+            raise IllegalArgumentException("bitWidth must be in 0..64")
+        self._w = bitWidth
+
+    def getBitWidth(self):
+        return self._w
+
+    def _unpack(self, n, input, inPos, output, outPos):
+        if not (isinstance(output, _np.ndarray) and output.dtype == _np.int64 and output.flags.c_contiguous):
+            raise IllegalArgumentException("output must be a contiguous int64 array")
+        if outPos < 0 or outPos + n > output.size:
+            raise IndexError("output too small")
+        nbytes = n * self._w // 8
+        buf = _np.frombuffer(input, _np.uint8) if not isinstance(input, _np.ndarray) else input.view(_np.uint8).reshape(-1)
+        if inPos < 0 or inPos + nbytes > buf.size:
+            raise IndexError("input too short")
+        src = _np.ascontiguousarray(buf[inPos:inPos + nbytes])
+        dst = output[outPos:outPos + n]
+        _raise_for(lib.pqd_unpack_i64(self._w, _ptr(src), src.size, _ptr(dst), n), "BytePackerForLong.unpack")
+
+    def unpack8Values(self, input, inPos, output, outPos):
+        self._unpack(8, input, inPos, output, outPos)
+
+    def unpack32Values(self, input, inPos, output, outPos):
+        self._unpack(32, input, inPos, output, outPos)
+
+
+class Packer:
+    """Packer.LITTLE_ENDIAN / Packer.BIG_ENDIAN factories (Packer.java:26-121).  ``newBytePackerVector``
+    is the plugin hook (Packer.java:92-111): here the device library is the plugin."""
+
+    def __init__(self, msb_first):
+        self._msb = msb_first
+
+    def newBytePacker(self, width):
+        return BytePacker(width, self._msb)
+
+    def newBytePackerVector(self, width):
+        if self._msb:
+            raise RuntimeError("Not currently supported!")  # Packer.java:61-64
+        if device_count() < 1:
+            raise RuntimeError("No enable java vector plugin on little endian architectures")  # Packer.java:104-108
+        return BytePacker(width, False)
+
+    def newBytePackerForLong(self, width):
+        if self._msb:
+            raise RuntimeError("MSB-first 64-bit packers are not on the decode path")
+        return BytePackerForLong(width)
+
+
+Packer.LITTLE_ENDIAN = Packer(False)
+Packer.BIG_ENDIAN = Packer(True)
 
 
 # ------------------------------------------------------------------------------- ValuesReader family

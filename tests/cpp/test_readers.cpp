@@ -131,6 +131,30 @@ int main() {
     EXPECT(throws<ParquetDecodingException>([&] { r3.readLong(); }));
   }
 
+  // BytePacker per-step interface: the vector step equals the scalar steps (TestByteBitPacking512VectorLE)
+  {
+    std::vector<uint8_t> raw(300);
+    for (size_t i = 0; i < raw.size(); ++i) raw[i] = (uint8_t)(i * 37 + 11);
+    bool ok = true;
+    for (int w = 0; w <= 32; ++w) {
+      BytePacker p(w);
+      int cnt = p.getUnpackCount();
+      std::vector<int32_t> a(64 + 2, -7), b(64, -7);
+      p.unpackValuesUsingVector(raw.data(), 3, a.data(), 1);
+      for (int g = 0; g < cnt / 8; ++g) p.unpack8Values(raw.data(), 3 + g * w, b.data(), g * 8);
+      for (int i = 0; i < cnt; ++i) ok = ok && a[1 + i] == b[i];
+      ok = ok && a[0] == -7 && a[1 + cnt] == -7;
+      if (w > 0 && w < 32) ok = ok && (uint32_t)b[0] == ((raw[3] | raw[4] << 8 | raw[5] << 16 | (uint32_t)raw[6] << 24 | (uint64_t)raw[7] << 32) & ((1ull << w) - 1));
+    }
+    EXPECT(ok);
+    BytePackerForLong pl(40);
+    int64_t out[8];
+    pl.unpack8Values(raw.data(), 0, out, 0);
+    uint64_t v0 = 0;
+    for (int b = 0; b < 5; ++b) v0 |= (uint64_t)raw[b] << (8 * b);
+    EXPECT((uint64_t)out[0] == v0);
+  }
+
   // PlainBinaryDictionary + readBytes: TestDictionary.testBinaryDictionary-style "a" + i % 50 strings
   {
     std::vector<std::string> words(50);

@@ -454,3 +454,45 @@ def test_host_entry_points_and_reader_mirror(gpu, orc):
     rd = pq.RunLengthBitPackingHybridValuesReader(2)
     rd.initFromPage(40, s)
     assert [rd.readInteger() for _ in range(40)] == [1, 2, 3, 0] * 10 and s.available() == 1
+
+
+def test_byte_packer_mirror(gpu, orc):
+    """Per-step interface: Packer.LITTLE_ENDIAN / BIG_ENDIAN .newBytePacker(w).unpack8Values /
+    unpack32Values, the plugin's unpackValuesUsingVector == the scalar packer for every width
+    (TestByteBitPacking512VectorLE.java:60-87), BytePackerForLong (TestByteBitPacking.java:149-198)."""
+    import parquet_java_amd as pq
+    rng = np.random.default_rng(31)
+    for w in range(0, 33):
+        raw = rng.integers(0, 256, 3 + 64 * 4 + 8, dtype=np.uint8)
+        for packer, msb in ((pq.Packer.LITTLE_ENDIAN.newBytePacker(w), False), (pq.Packer.BIG_ENDIAN.newBytePacker(w), True)):
+            assert packer.getBitWidth() == w
+            out = np.full(48, -7, np.int32)
+            packer.unpack8Values(raw, 3, out, 5)
+            exp = orc.unpack8(w, raw[3:3 + w], msb_first=msb) if w else np.zeros(8, np.int32)
+            assert (out[5:13] == exp).all() and (out[:5] == -7).all() and (out[13:] == -7).all(), (w, msb)
+            packer.unpack32Values(raw.tobytes(), 1, out, 16)
+            exp32 = np.concatenate([orc.unpack8(w, raw[1 + g * w:1 + (g + 1) * w], msb_first=msb) for g in range(4)]) \
+                if w else np.zeros(32, np.int32)
+            assert (out[16:48] == exp32).all(), (w, msb)
+        vec = pq.Packer.LITTLE_ENDIAN.newBytePackerVector(w)
+        cnt = vec.getUnpackCount()
+        assert cnt == (0 if w == 0 else 64 if w == 8 else 32 if w < 16 else 16)
+        out = np.full(cnt + 2, -7, np.int32)
+        vec.unpackValuesUsingVector(raw, 2, out, 1)
+        scalar = np.zeros(max(cnt, 1), np.int32)
+        sp = pq.Packer.LITTLE_ENDIAN.newBytePacker(w)
+        for g in range(cnt // 8):
+            sp.unpack8Values(raw, 2 + g * w, scalar, g * 8)
+        assert (out[1:1 + cnt] == scalar[:cnt]).all() and out[0] == -7 and out[-1] == -7, w
+    with pytest.raises(RuntimeError):
+        pq.Packer.BIG_ENDIAN.newBytePackerVector(3)
+    with pytest.raises(IndexError):
+        pq.Packer.LITTLE_ENDIAN.newBytePacker(9).unpack8Values(np.zeros(8, np.uint8), 0, np.zeros(8, np.int32), 0)
+    for w in (0, 1, 7, 31, 33, 47, 64):
+        raw = rng.integers(0, 256, 2 + 4 * w, dtype=np.uint8)
+        p = pq.Packer.LITTLE_ENDIAN.newBytePackerForLong(w)
+        out = np.zeros(40, np.int64)
+        p.unpack8Values(raw, 2, out, 0)
+        p.unpack32Values(raw, 2, out, 8)
+        exp = np.concatenate([orc.unpack8(w, raw[2 + g * w:2 + (g + 1) * w], long=True) for g in range(4)]) if w else np.zeros(32, np.int64)
+        assert (out[:8] == exp[:8]).all() and (out[8:] == exp).all(), w
