@@ -416,12 +416,15 @@ __device__ __forceinline__ void plan_round(PlanState& st, u32x4* win4, RleSeg* s
 
 // Pool chunk p is reserved for page p; a page that has nothing for the consuming kernel leaves an
 // empty chunk there (v0 == v1), so that the consumers can take every slot as it comes.
-__device__ __forceinline__ void write_empty_chunk(RleSeg* pool, uint32_t page) {
+__device__ __forceinline__ void write_empty_chunk(RleSeg* pool, uint32_t slot, uint32_t page) {
   RleChunkHead hd = {};
   hd.data = (uint64_t)(uintptr_t)pool;  // any readable address
   hd.page = page;
-  *reinterpret_cast<RleChunkHead*>(pool + (size_t)page * SEG_CHUNK + SEG_HEAD_SLOT) = hd;
+  *reinterpret_cast<RleChunkHead*>(pool + (size_t)slot * SEG_CHUNK + SEG_HEAD_SLOT) = hd;
 }
+__device__ __forceinline__ void write_empty_chunk(RleSeg* pool, uint32_t page) { write_empty_chunk(pool, page, page); }
+
+constexpr int BULK_LOADS = 8;  // run headers a lane checks per step of the bulk verification
 
 // ---------------------------------------------------------------------------------------------
 // The plan kernel: one wave per page, pages of any length.  The plan is a list of chunks taken from
@@ -546,7 +549,130 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   uint32_t emitted = 0;  // chunks written for this page
   const uint32_t span = want_dict ? DS_TILE_VALUES : SEG_CHUNK_SPAN;  // values per chunk, at most
   bool fallback = false;
-  for (;;) {
+
+  // ---- long pages that start with many equal bit-packed runs (non-repeating data as parquet-java
+  // writes it: 63-group runs behind 1-byte headers).  Where run r starts follows from r alone, so the
+  // lanes check the headers of all runs, BULK_LOADS each per step, and the chunks that lie wholly
+  // inside the verified prefix are written straight from arithmetic: no staging, no searches.  What
+  // remains of the page (the last runs, anything irregular) goes through the loop below.
+  if (w > 0 && n_values >= 2u * span && (uint64_t)pos + 16 <= end) {
+    uint32_t hx;
+    __builtin_memcpy(&hx, d.data + pos, 4);
+    const uint32_t b0 = hx & 0xFFu, b1 = (hx >> 8) & 0xFFu, b2 = (hx >> 16) & 0xFFu, b3 = hx >> 24;
+    uint32_t header, nb;
+    if (!(b0 & 0x80u)) {
+      header = b0;
+      nb = 1;
+    } else if (!(b1 & 0x80u)) {
+      header = (b0 & 0x7Fu) | (b1 << 7);
+      nb = 2;
+    } else if (!(b2 & 0x80u)) {
+      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | (b2 << 14);
+      nb = 3;
+    } else {
+      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | ((b2 & 0x7Fu) << 14) | (b3 << 21);
+      nb = (b3 & 0x80u) ? 0u : 4u;
+    }
+    const uint32_t g0 = header >> 1;
+    const uint64_t run_bytes = (uint64_t)g0 * w + nb;
+    if (nb != 0 && (header & 1u) && g0 >= 1 && run_bytes >= 24 && (uint64_t)g0 * w <= (uint64_t)PLAN_SEG_MAX_BYTES) {
+      const uint32_t S = (uint32_t)run_bytes, V = g0 * 8;
+      const uint32_t hmask = nb == 4 ? ~0u : (1u << (8 * nb)) - 1u, hbytes = hx & hmask;
+      uint32_t rmax = (end - pos) / S;  // runs wholly inside the stream ...
+      if (n_values / V < rmax) rmax = n_values / V;  // ... all of whose values are wanted
+      uint32_t reg = rmax;  // leading runs with exactly that header
+      for (uint32_t base = 0; base < rmax; base += 64u * BULK_LOADS) {
+        uint32_t x[BULK_LOADS];
+#pragma unroll
+        for (int k = 0; k < BULK_LOADS; ++k) {
+          const uint32_t r = base + (uint32_t)k * 64u + tid;
+          x[k] = hbytes;
+          if (r < rmax) __builtin_memcpy(&x[k], d.data + pos + (uint64_t)r * S, 4);
+        }
+        uint32_t first_miss = ~0u;
+#pragma unroll
+        for (int k = BULK_LOADS - 1; k >= 0; --k) {
+          const uint64_t miss = __builtin_amdgcn_ballot_w64((x[k] & hmask) != hbytes);
+          if (miss) first_miss = base + (uint32_t)k * 64u + (uint32_t)__builtin_ctzll(miss);
+        }
+        if (first_miss != ~0u) {
+          reg = first_miss;
+          break;
+        }
+      }
+      uint32_t sp = ((229u * V) / SEG_BLOCK) * SEG_BLOCK;  // values per chunk: at most SEG_GEN_MAX runs touch it
+      if (sp > span) sp = span;
+      const uint32_t vreg = reg * V;
+      const uint32_t n_bulk = sp ? vreg / sp : 0u;
+      if (n_bulk >= 2) {
+        if (tid == 0) st.chunk_slot = atomicAdd(cursor, n_bulk - 1u);
+        __syncthreads();
+        const uint32_t tail0 = n_pages + st.chunk_slot;  // chunks 1.. of this page; chunk 0 sits at the page's own slot
+        if (page >= pool_chunks || (uint64_t)tail0 + (n_bulk - 1u) > pool_chunks) {
+          // the pool is too small for this page: the slots taken must still read as chunks
+          for (uint32_t c = 1 + tid; c < n_bulk; c += PLAN_THREADS)
+            if (tail0 + c - 1 < pool_chunks) write_empty_chunk(pool, tail0 + c - 1, page);
+          fallback = true;
+        } else {
+          for (uint32_t c = 0; c < n_bulk; ++c) {
+            const uint32_t a = c * sp, b = a + sp;
+            const uint32_t r_first = a / V, r_last = (b - 1u) / V, k = r_last - r_first + 1u;
+            RleSeg* out = pool + (size_t)(c == 0 ? page : tail0 + c - 1) * SEG_CHUNK;
+            for (uint32_t i = tid; i <= k; i += PLAN_THREADS) {
+              const uint32_t r = r_first + i;
+              RleSeg sg;
+              sg.start4 = i < k ? ((r * V) << 2) | SEG_PACKED_BIT : b << 2;  // the last one is the sentinel
+              sg.src = i < k ? pos + r * S + nb : 0u;
+              out[i] = sg;
+            }
+            if (tid == 0) {
+              RleChunkHead hd = {};
+              hd.data = (uint64_t)(uintptr_t)d.data;
+              hd.out = (uint64_t)(uintptr_t)d.out;
+              hd.v0 = a;
+              hd.v1 = b;
+              hd.nseg = k;
+              hd.w = w;
+              hd.data_len = d.data_len;
+              hd.stream_end = end;
+              hd.page = page;
+              hd.dict = (uint64_t)(uintptr_t)d.dict;
+              hd.dict_len = d.dict_len;
+              *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
+            }
+            if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
+              uint32_t packed = 0;
+#pragma unroll
+              for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t first = a + (tid * 4 + q) * SEG_BLOCK;
+                const uint32_t idx = first >= b ? k - 1u : first / V - r_first;
+                packed |= idx << (8 * q);
+              }
+              reinterpret_cast<uint32_t*>(out + SEG_TABLE_SLOT)[tid] = packed;
+            }
+          }
+          // the runs of the prefix that reach past the last bulk chunk stay staged
+          const uint32_t cut = n_bulk * sp;
+          const uint32_t r_rem = cut < vreg ? cut / V : reg;
+          for (uint32_t i = tid; i < reg - r_rem; i += PLAN_THREADS) {
+            stage[i].start4 = (((r_rem + i) * V) << 2) | SEG_PACKED_BIT;
+            stage[i].src = pos + (r_rem + i) * S + nb;
+          }
+          if (tid == 0) {
+            st.pos = pos + reg * S;
+            st.vals = vreg;
+            st.nstage = reg - r_rem;
+            st.done = vreg >= n_values ? 1u : 0u;
+          }
+          v0 = cut;
+          emitted = n_bulk;
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  for (; !fallback;) {
     bool fresh = false;
     if (st.need_round) {
       plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);

@@ -496,3 +496,78 @@ def test_byte_packer_mirror(gpu, orc):
         p.unpack32Values(raw, 2, out, 8)
         exp = np.concatenate([orc.unpack8(w, raw[2 + g * w:2 + (g + 1) * w], long=True) for g in range(4)]) if w else np.zeros(32, np.int64)
         assert (out[:8] == exp[:8]).all() and (out[8:] == exp).all(), w
+
+
+def hybrid_stream(orc, w, runs):
+    """Hand-built hybrid stream.  runs: ('p', groups, values[groups*8]) or ('r', count, value)."""
+    out = bytearray()
+
+    def varint(h):
+        while h >= 0x80:
+            out.append((h & 0x7F) | 0x80)
+            h >>= 7
+        out.append(h)
+    for r in runs:
+        if r[0] == 'p':
+            varint((r[1] << 1) | 1)
+            out.extend(orc.pack(w, np.asarray(r[2], np.int32)).tobytes())
+        else:
+            varint(r[1] << 1)
+            out.extend(int(r[2]).to_bytes((w + 7) // 8, "little"))
+    return np.frombuffer(bytes(out), np.uint8).copy()
+
+
+def test_rle_long_regular_pages(gpu, orc, rle_path):
+    """Pages that start with many equal bit-packed runs (planned in bulk) in every shape around the
+    bulk path's edges: run lengths other than 63 groups, multi-byte headers, an irregular run part
+    way, a cut-off stream, fewer values wanted than the stream holds."""
+    rng = np.random.default_rng(77)
+    cases = []
+
+    def regular(w, groups, n_runs):
+        return [('p', groups, rand_vals(rng, w, groups * 8)) for _ in range(n_runs)]
+    for w, groups, n_runs in ((8, 63, 400), (3, 63, 600), (16, 63, 140), (32, 1, 9000), (24, 1, 20000), (5, 200, 100),
+                              (12, 2, 9000), (1, 700, 40), (7, 64, 300)):
+        runs = regular(w, groups, n_runs)
+        total = groups * 8 * n_runs
+        data = hybrid_stream(orc, w, runs)
+        cases.append((w, data, total, 0))
+        cases.append((w, data, total - 5, 0))               # the last run is not wholly wanted
+        cases.append((w, data, total + 9, 0))               # reads past the end of the stream
+        cases.append((w, data[:data.size - 7], total, 0))   # the last run is cut short
+        cases.append((w, data[:data.size * 2 // 3], total, 0))
+        # an RLE run, a shorter packed run and a packed run with another header part way
+        mid = n_runs * 2 // 3
+        mixed = runs[:mid] + [('r', 100, 1)] + runs[mid:mid + 3] + [('p', max(groups - 1, 1), rand_vals(rng, w, max(groups - 1, 1) * 8))] + runs[mid + 3:]
+        tot2 = total + 100 + max(groups - 1, 1) * 8
+        cases.append((w, hybrid_stream(orc, w, mixed), tot2, 0))
+        cases.append((w, hybrid_stream(orc, w, mixed), tot2 // 2, 0))
+    # V1 levels and ids with their prefixes
+    import parquet_java_amd as pq
+    runs = regular(2, 63, 300)
+    body = hybrid_stream(orc, 2, runs)
+    cases.append((2, np.concatenate([np.frombuffer(struct.pack("<i", body.size), np.uint8), body, np.full(9, 0xEE, np.uint8)]),
+                  63 * 8 * 300, pq.F_LENGTH_PREFIX))
+    body = hybrid_stream(orc, 11, regular(11, 63, 250))
+    cases.append((0, np.concatenate([np.array([11], np.uint8), body]), 63 * 8 * 250, pq.F_WIDTH_PREFIX))
+    check_rle(gpu, orc, cases)
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+def test_dictionary_long_regular_pages(gpu, orc, elem, dict_path):
+    import parquet_java_amd as pq
+    rng = np.random.default_rng(78)
+    pages, expect = [], []
+    for w, groups, n_runs, cut in ((10, 63, 300, 0), (16, 63, 130, 11), (4, 63, 500, 0), (12, 7, 2000, 3)):
+        dic = rng.integers(-(1 << 31), 1 << 31, 1 << w).astype(np.int32 if elem == 4 else np.int64)
+        if elem == 8:
+            dic = dic * np.int64(0x100000001)
+        runs = [('p', groups, rand_vals(rng, w, groups * 8)) for _ in range(n_runs)]
+        runs.insert(n_runs // 2, ('r', 4000, 5))
+        data = np.concatenate([np.array([w], np.uint8), hybrid_stream(orc, w, runs)])
+        n = groups * 8 * n_runs + 4000 - cut
+        pages.append(gpu.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        expect.append(orc.dict_decode(data, dic, n))
+    for (st, written, _, out, guard), (ost, ovals) in zip(gpu.decode_pages(pages), expect):
+        assert st == ost == 0 and written == ovals.size
+        assert (out.view(ovals.dtype) == ovals).all() and (guard == 0xA5).all()
