@@ -208,6 +208,86 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
   }
 }
 
+// One tile of a REGULAR chunk: every segment is a whole bit-packed run of `run_values` values and
+// `run_stride` stream bytes, one behind the other (the plan kernel's bulk path marks such chunks).
+// The run of a unit follows from its index, so there is no table, no search and no LDS traffic:
+// a division by the (wave-uniform) run length, one load, the extracts, one store.
+template <bool WIDE>
+__device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t start0, uint32_t src0, uint32_t run_values,
+                                                    uint32_t run_stride, float rcp_values, uint32_t t0, uint32_t v1,
+                                                    PQD_GLOBAL uint32_t* out, uint32_t tid) {
+  constexpr int NW = WIDE ? 5 : 3;
+  const uint32_t max_wi = h.last_word + 1 - NW;  // a regular run is at least 24 bytes: the page holds a unit load
+  uint32_t wi[EX_UNITS], sh[EX_UNITS], delta[EX_UNITS];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    const uint32_t rel = (g0 < v1 ? g0 : t0) - start0;  // below 2^17: exact as a float
+    uint32_t q = (uint32_t)((float)rel * rcp_values);
+    q -= q * run_values > rel ? 1u : 0u;
+    q += (q + 1u) * run_values <= rel ? 1u : 0u;
+    const uint32_t byte0 = h.in_off + src0 + q * run_stride;
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (rel - q * run_values) * h.w;
+    const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
+    delta[k] = w_i > max_wi ? w_i - max_wi : 0u;  // the page's last dwords: load what is there, shift below
+    wi[k] = w_i - delta[k];
+    sh[k] = bitrel & 31u;
+  }
+  uint32_t d[EX_UNITS][NW];
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    if (WIDE) {
+      const u32x4_a4 a = *(const PQD_GLOBAL u32x4_a4*)(h.words + wi[k]);
+      d[k][0] = a.x;
+      d[k][1] = a.y;
+      d[k][2] = a.z;
+      d[k][WIDE ? 3 : 0] = a.w;
+      d[k][WIDE ? 4 : 0] = h.words[wi[k] + 4];
+    } else {
+      const u32x3_a4 a = *(const PQD_GLOBAL u32x3_a4*)(h.words + wi[k]);
+      d[k][0] = a.x;
+      d[k][1] = a.y;
+      d[k][2] = a.z;
+    }
+  }
+  const uint32_t mask = mask32(h.w);
+#pragma unroll
+  for (int k = 0; k < EX_UNITS; ++k) {
+    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    if (delta[k]) {  // rare
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = j + 1; i < NW; ++i) x = (uint32_t)(i - j) == delta[k] ? d[k][i] : x;
+        d[k][j] = x;
+      }
+    }
+    uint32_t a0, a1, a2, a3;
+    if (WIDE) {
+      Window5 wnd = {d[k][0], d[k][1], d[k][2], d[k][WIDE ? 3 : 0], d[k][WIDE ? 4 : 0]};
+      wnd.shr(sh[k]);
+      a0 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a1 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a2 = wnd.d0 & mask;
+      wnd.drop(h.w);
+      a3 = wnd.d0 & mask;
+    } else {
+      const uint32_t lo = funnel_shr(d[k][0], d[k][1], sh[k]), hi = funnel_shr(d[k][1], d[k][2], sh[k]);
+      a0 = ex_unit_value(lo, hi, h.w, 0);
+      a1 = ex_unit_value(lo, hi, h.w, 1);
+      a2 = ex_unit_value(lo, hi, h.w, 2);
+      a3 = ex_unit_value(lo, hi, h.w, 3);
+    }
+    if (g0 < v1) {  // v1 of a regular chunk is a multiple of SEG_BLOCK: whole units only
+      const u32x4_a4 r4 = {a0, a1, a2, a3};
+      *(PQD_GLOBAL u32x4_a4*)(out + g0) = r4;
+    }
+  }
+}
+
 __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                            const uint32_t* __restrict__ cursor, uint32_t n_pages) {
   __shared__ RleSeg cs_buf[SEG_CHUNK];
@@ -240,7 +320,19 @@ __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restr
     h.tail_mask = (end_bytes & 3u) ? ((1u << (8 * (end_bytes & 3u))) - 1u) : 0u;
     h.w = uni(hd->w);
     PQD_GLOBAL uint32_t* out = (PQD_GLOBAL uint32_t*)out_addr;
-    if (h.w <= 16) {
+    const uint32_t run_values = uni(hd->reserved[0]);
+    if (run_values) {  // a chunk of equal bit-packed runs
+      const uint32_t run_stride = uni(hd->reserved[1]);
+      const uint32_t start0 = uni(cs[0].start4) >> 2, src0 = uni(cs[0].src);
+      const float rcp_values = 1.0f / (float)run_values;
+      if (h.w <= 16) {
+        for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE)
+          expand_regular_tile<false>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
+      } else {
+        for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE)
+          expand_regular_tile<true>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
+      }
+    } else if (h.w <= 16) {
       for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<false>(cs, h, v0, t0, v1, out, tid, wave);
     } else {
       for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<true>(cs, h, v0, t0, v1, out, tid, wave);

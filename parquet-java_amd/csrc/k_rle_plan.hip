@@ -638,6 +638,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
               hd.page = page;
               hd.dict = (uint64_t)(uintptr_t)d.dict;
               hd.dict_len = d.dict_len;
+              hd.reserved[0] = V;  // marks the chunk as regular: run r0 + i = values start0 + i*V, bytes src0 + i*S
+              hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
@@ -736,6 +738,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
         hd->page = page;
         hd->dict = (uint64_t)(uintptr_t)d.dict;
         hd->dict_len = d.dict_len;
+        hd->reserved[0] = 0;  // not a chunk of equal runs
+        hd->reserved[1] = 0;
       }
       __syncthreads();
       uint8_t* table = reinterpret_cast<uint8_t*>(chunk + SEG_TABLE_SLOT);

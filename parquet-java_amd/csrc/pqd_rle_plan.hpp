@@ -53,7 +53,8 @@ struct RleChunkHead {
   uint32_t page;
   uint32_t dict_len;    // dictionary pages: entries of the dictionary ...
   uint64_t dict;        // ... and where it is
-  uint32_t reserved[2];
+  uint32_t reserved[2];  // [0] != 0: every segment is a whole bit-packed run of [0] values and [1] stream
+                         // bytes, one right behind the other (k_rle_expand then needs no search)
 };
 static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
 
