@@ -614,7 +614,32 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
             if (tail0 + c - 1 < pool_chunks) write_empty_chunk(pool, tail0 + c - 1, page);
           fallback = true;
         } else {
-          for (uint32_t c = 0; c < n_bulk; ++c) {
+          // The expansion kernel reads only the first segment and the header of a regular chunk: for
+          // plain hybrid pages every lane writes whole chunks.  The dictionary kernel has no such path
+          // and gets the full segment list and block table.
+          for (uint32_t c = tid; !want_dict && c < n_bulk; c += PLAN_THREADS) {
+            const uint32_t a = c * sp, b = a + sp;
+            const uint32_t r_first = a / V, r_last = (b - 1u) / V;
+            RleSeg* out = pool + (size_t)(c == 0 ? page : tail0 + c - 1) * SEG_CHUNK;
+            RleSeg sg;
+            sg.start4 = ((r_first * V) << 2) | SEG_PACKED_BIT;
+            sg.src = pos + r_first * S + nb;
+            out[0] = sg;
+            RleChunkHead hd = {};
+            hd.data = (uint64_t)(uintptr_t)d.data;
+            hd.out = (uint64_t)(uintptr_t)d.out;
+            hd.v0 = a;
+            hd.v1 = b;
+            hd.nseg = r_last - r_first + 1u;
+            hd.w = w;
+            hd.data_len = d.data_len;
+            hd.stream_end = end;
+            hd.page = page;
+            hd.reserved[0] = V;
+            hd.reserved[1] = S;
+            *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
+          }
+          for (uint32_t c = 0; want_dict && c < n_bulk; ++c) {
             const uint32_t a = c * sp, b = a + sp;
             const uint32_t r_first = a / V, r_last = (b - 1u) / V, k = r_last - r_first + 1u;
             RleSeg* out = pool + (size_t)(c == 0 ? page : tail0 + c - 1) * SEG_CHUNK;
