@@ -426,6 +426,24 @@ __device__ __forceinline__ void write_empty_chunk(RleSeg* pool, uint32_t page) {
 
 constexpr int BULK_LOADS = 8;  // run headers a lane checks per step of the bulk verification
 
+// Varint of at most four bytes from the dword that starts with it (nb = 0: longer than that).
+__device__ __forceinline__ void varint_of_dword(uint32_t x, uint32_t& header, uint32_t& nb) {
+  const uint32_t b0 = x & 0xFFu, b1 = (x >> 8) & 0xFFu, b2 = (x >> 16) & 0xFFu, b3 = x >> 24;
+  if (!(b0 & 0x80u)) {
+    header = b0;
+    nb = 1;
+  } else if (!(b1 & 0x80u)) {
+    header = (b0 & 0x7Fu) | (b1 << 7);
+    nb = 2;
+  } else if (!(b2 & 0x80u)) {
+    header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | (b2 << 14);
+    nb = 3;
+  } else {
+    header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | ((b2 & 0x7Fu) << 14) | (b3 << 21);
+    nb = (b3 & 0x80u) ? 0u : 4u;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The plan kernel: one wave per page, pages of any length.  The plan is a list of chunks taken from
 // a shared pool (pqd_rle_plan.hpp): plain hybrid pages (want_dict == 0: levels, booleans, ids as
@@ -550,29 +568,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   const uint32_t span = want_dict ? DS_TILE_VALUES : SEG_CHUNK_SPAN;  // values per chunk, at most
   bool fallback = false;
 
-  // ---- long pages that start with many equal bit-packed runs (non-repeating data as parquet-java
-  // writes it: 63-group runs behind 1-byte headers).  Where run r starts follows from r alone, so the
-  // lanes check the headers of all runs, BULK_LOADS each per step, and the chunks that lie wholly
-  // inside the verified prefix are written straight from arithmetic: no staging, no searches.  What
-  // remains of the page (the last runs, anything irregular) goes through the loop below.
-  if (w > 0 && n_values >= 2u * span && (uint64_t)pos + 16 <= end) {
+  // ---- pages that start with equal bit-packed runs (non-repeating data as parquet-java writes it:
+  // 63-group runs behind 1-byte headers).  Where run r starts follows from r alone, so the lanes
+  // check the headers of all runs, BULK_LOADS each per step.  Of a long page, the chunks that lie
+  // wholly inside the verified prefix are written straight from arithmetic: no staging, no searches.
+  // What remains of the page (the last runs, anything irregular) goes through the loop below.
+  if (w > 0 && (uint64_t)pos + 16 <= end) {
     uint32_t hx;
     __builtin_memcpy(&hx, d.data + pos, 4);
-    const uint32_t b0 = hx & 0xFFu, b1 = (hx >> 8) & 0xFFu, b2 = (hx >> 16) & 0xFFu, b3 = hx >> 24;
     uint32_t header, nb;
-    if (!(b0 & 0x80u)) {
-      header = b0;
-      nb = 1;
-    } else if (!(b1 & 0x80u)) {
-      header = (b0 & 0x7Fu) | (b1 << 7);
-      nb = 2;
-    } else if (!(b2 & 0x80u)) {
-      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | (b2 << 14);
-      nb = 3;
-    } else {
-      header = (b0 & 0x7Fu) | ((b1 & 0x7Fu) << 7) | ((b2 & 0x7Fu) << 14) | (b3 << 21);
-      nb = (b3 & 0x80u) ? 0u : 4u;
-    }
+    varint_of_dword(hx, header, nb);
     const uint32_t g0 = header >> 1;
     const uint64_t run_bytes = (uint64_t)g0 * w + nb;
     if (nb != 0 && (header & 1u) && g0 >= 1 && run_bytes >= 24 && (uint64_t)g0 * w <= (uint64_t)PLAN_SEG_MAX_BYTES) {
@@ -695,13 +700,53 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
           emitted = n_bulk;
         }
         __syncthreads();
+      } else if (reg >= 2) {
+        // a short page: its leading equal runs go to the stage as they are, the loop below cuts them
+        const uint32_t take = reg < (uint32_t)SEG_GEN_MAX ? reg : (uint32_t)SEG_GEN_MAX;
+        for (uint32_t i = tid; i < take; i += PLAN_THREADS) {
+          stage[i].start4 = ((i * V) << 2) | SEG_PACKED_BIT;
+          stage[i].src = pos + i * S + nb;
+        }
+        if (tid == 0) {
+          st.pos = pos + take * S;
+          st.vals = take * V;
+          st.nstage = take;
+          st.done = take * V >= n_values ? 1u : 0u;
+          if (take < reg) st.next_stride = st.prev_stride = S;  // more of the same follows: strided rounds
+        }
+        __syncthreads();
+      }
+      // The run behind the prefix: pages of non-repeating data end with one shorter bit-packed run.
+      // If it lies wholly inside the stream and yields all the values still wanted, it is staged
+      // here and the page is done (the loop below then only cuts the chunks).
+      const bool prefix_staged = n_bulk >= 2 ? !fallback : (reg >= 2 && reg <= (uint32_t)SEG_GEN_MAX);
+      const uint64_t p2 = (uint64_t)pos + (uint64_t)reg * S;
+      if (prefix_staged && vreg < n_values && p2 + 4 <= end) {
+        uint32_t hx2, header2, nb2;
+        __builtin_memcpy(&hx2, d.data + p2, 4);
+        varint_of_dword(hx2, header2, nb2);
+        const uint32_t g2 = header2 >> 1;
+        const uint32_t ns = st.nstage;
+        if (nb2 != 0 && (header2 & 1u) && g2 >= 1 && (uint64_t)g2 * w <= (uint64_t)PLAN_SEG_MAX_BYTES &&
+            p2 + nb2 + (uint64_t)g2 * w <= end && (uint64_t)vreg + (uint64_t)g2 * 8 >= n_values && ns < (uint32_t)SEG_GEN_MAX) {
+          __syncthreads();
+          if (tid == 0) {
+            stage[ns].start4 = (vreg << 2) | SEG_PACKED_BIT;
+            stage[ns].src = (uint32_t)p2 + nb2;
+            st.nstage = ns + 1;
+            st.vals = n_values;
+            st.pos = (uint32_t)p2 + nb2 + g2 * w;  // readNext takes the whole run when it reads the header
+            st.done = 1;
+          }
+          __syncthreads();
+        }
       }
     }
   }
 
   for (; !fallback;) {
     bool fresh = false;
-    if (st.need_round) {
+    if (st.need_round && !st.done) {
       plan_round(st, win4, stage, d.data, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
       fresh = true;
     }
