@@ -233,11 +233,9 @@ __device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg
   st.pos = pos;
 }
 
+// One page, decoded by the whole workgroup.
 template <int ELEM, bool HAS_DICT>
-__global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
-                                                           pqd_page_result* __restrict__ results,
-                                                           uint32_t n_pages,
-                                                           const RlePagePlan* __restrict__ only_fallback) {
+__device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_result* __restrict__ results, uint32_t page) {
   __shared__ u32x4 win4[WINDOW_PIECES];
   __shared__ uint32_t seg_start[MAX_SEGS + 1];
   __shared__ uint32_t seg_src[MAX_SEGS];
@@ -245,10 +243,6 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
   __shared__ RleState st;
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
 
-  const uint32_t page = blockIdx.x;
-  if (page >= n_pages) return;
-  // when a plan array is given, only the pages the planned path could not take are decoded here
-  if (only_fallback && !(only_fallback[page].flags & PLAN_F_FALLBACK)) return;
   const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
 
@@ -422,19 +416,40 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
   }
 }
 
-
+// Without a plan array: workgroup b decodes page b.  With one: only the pages the planned path could
+// not take are decoded here; the plan kernel has listed them (entry i of the list sits in
+// only_fallback[i].reserved, their number in *fallback_count), and a small grid strides over the list.
+template <int ELEM, bool HAS_DICT>
+__global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
+                                                           pqd_page_result* __restrict__ results,
+                                                           uint32_t n_pages,
+                                                           const RlePagePlan* __restrict__ only_fallback,
+                                                           const uint32_t* __restrict__ fallback_count) {
+  if (!only_fallback) {
+    if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x);
+    return;
+  }
+  uint32_t n = *fallback_count;
+  if (n > n_pages) n = n_pages;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t page = only_fallback[i].reserved;
+    if (page < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, page);
+    __syncthreads();  // the next page reuses the LDS
+  }
+}
 
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
-                            bool has_dict, const void* only_fallback_plans, hipStream_t stream) {
+                            bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
+                            hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  const dim3 grid(n_pages), block(RLE_THREADS);
   const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
+  const dim3 grid(pl && n_pages > 512u ? 512u : n_pages), block(RLE_THREADS);
   if (!has_dict)
-    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl);
+    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
   else if (elem == 4)
-    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl);
+    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
   else
-    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl);
+    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
   return hipGetLastError();
 }
 

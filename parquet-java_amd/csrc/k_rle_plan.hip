@@ -517,10 +517,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
       r.bytes_consumed = early == PQD_OK ? (consumed_override != ~0u ? consumed_override : pos) : 0;
       r.reserved = 0;
       results[page] = r;
-      RlePagePlan pl = {};
-      pl.status = early;
-      pl.flags = PLAN_F_DONE;
-      plans[page] = pl;
+      plans[page].flags = PLAN_F_DONE;
       if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
@@ -539,9 +536,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   }
   if (not_planned) {
     if (tid == 0) {
-      RlePagePlan pl = {};
-      pl.flags = PLAN_F_FALLBACK;
-      plans[page] = pl;
+      plans[page].flags = PLAN_F_FALLBACK;
+      plans[atomicAdd(cursor + 1, 1u)].reserved = page;  // the generic kernel's work list
       if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
@@ -858,9 +854,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   }
   if (tid == 0) {
     if (emitted == 0 && page < pool_chunks) write_empty_chunk(pool, page);
-    RlePagePlan pl = {};
-    pl.flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
-    plans[page] = pl;
+    plans[page].flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
+    if (fallback) plans[atomicAdd(cursor + 1, 1u)].reserved = page;  // the generic kernel's work list
     if (!fallback) {
       pqd_page_result r;
       r.status = st.status;

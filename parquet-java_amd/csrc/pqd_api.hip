@@ -401,7 +401,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
     case PQD_ENC_RLE:
       if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_RLE produces 4-byte values");
       if (!use_planned_rle_path()) {
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, nullptr, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, nullptr, nullptr, s));
       } else {
         // 1. header walk of every page -> chunks of run segments in the pool
         // 2. expansion of all chunks (workgroups take chunks from a counter)
@@ -412,13 +412,13 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, false, 4, s));
         PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, s));
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, ps.counters + 1, s));
       }
       return PQD_OK;
     case PQD_ENC_RLE_DICTIONARY:
       if (elem_size != 4 && elem_size != 8) return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");
       if (!use_sliced_dictionary_path()) {
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, nullptr, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, nullptr, nullptr, s));
       } else {
         // 1. header walk of every page (one wave per page) -> chunks of run segments in the pool
         // 2. expansion + sliced LDS gather, chunk by chunk
@@ -433,7 +433,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if ((st = phase_mark(1, s))) return st;
         PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, elem_size, s));
         if ((st = phase_mark(2, s))) return st;
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s));
         if ((st = phase_mark(3, s))) return st;
       }
       return PQD_OK;
