@@ -231,17 +231,24 @@ constexpr int PLAN_WINDOW = 16 * PLAN_SLOTS;  // bytes of a contiguous round
 constexpr uint32_t NXT_COMPLEX = 0xFFFFu, NXT_STOP = 0xFFFEu;
 
 // Parallel planning of a contiguous header window (all lanes).  Every lane decodes the sixteen
-// candidate headers that start at its own bytes and writes where each would lead (`nxt`); lane 0
-// follows that chain from the stream position, which is one LDS read per run; then the runs found
-// are turned into segments 64 at a time, their output positions by a wave prefix sum.  Runs the
-// parallel rules do not cover (see parse_cand; also anything that touches the end of the stream)
-// stop the chain: the serial walk takes that one run and the next round starts behind it.
-__device__ __forceinline__ void plan_window(PlanState& st, const u32x4* win4, uint16_t* nxt, uint16_t* list, RleSeg* stage,
-                                            uint32_t end, uint32_t w, uint32_t n_values, uint32_t seg_limit, uint32_t tid) {
+// candidate headers that start at its own bytes and writes where each would lead (`nxt`).  The chain
+// of real headers from the stream position is then found in three steps: every lane resolves, for
+// each of its sixteen bytes, where a chain entering there leaves the lane's block (`exitp`, back to
+// front, one LDS read per byte); lane 0 hops from block to block (at most 64 hops, whatever the
+// number of runs) and notes where the chain enters each block; every lane lists the runs of its
+// own block from that entry, and a wave prefix sum puts the lists one behind the other.  Then the
+// runs are turned into segments 64 at a time, their output positions by a wave prefix sum.  Runs
+// the parallel rules do not cover (see parse_cand; also anything that touches the end of the
+// stream) stop the chain: the serial walk takes that one run and the next round starts behind it.
+// `exitp` (1024 entries) doubles as the lanes' private lists; `entry_of` has one entry per lane.
+__device__ __forceinline__ void plan_window(PlanState& st, const u32x4* win4, uint16_t* nxt, uint16_t* list, uint16_t* exitp,
+                                            uint16_t* entry_of, RleSeg* stage, uint32_t end, uint32_t w, uint32_t n_values,
+                                            uint32_t seg_limit, uint32_t tid) {
   const uint32_t pos0 = st.round_pos0;
   const uint32_t entry = st.pos - pos0;
   const uint32_t vb = (w + 7) >> 3;
   const bool to_end = (uint64_t)pos0 + PLAN_WINDOW >= end;  // the window holds the rest of the stream
+  const uint32_t block_end = 16 * tid + 16;
   // ---- A. candidates
   {
     const u32x4 a = win4[tid], b = win4[tid + 1];  // win4[PLAN_SLOTS] is zero
@@ -264,23 +271,58 @@ __device__ __forceinline__ void plan_window(PlanState& st, const u32x4* win4, ui
                    (uint32_t)out[4] | ((uint32_t)out[5] << 16), (uint32_t)out[6] | ((uint32_t)out[7] << 16)};
     dst[1] = u32x4{(uint32_t)out[8] | ((uint32_t)out[9] << 16), (uint32_t)out[10] | ((uint32_t)out[11] << 16),
                    (uint32_t)out[12] | ((uint32_t)out[13] << 16), (uint32_t)out[14] | ((uint32_t)out[15] << 16)};
+    // ---- B1. where a chain that enters at byte j leaves this block: a position at or past the
+    // block's end, or the position inside the block at which the chain stops.  A candidate leads
+    // forward, so the entries behind j are known when j's turn comes.
+#pragma unroll
+    for (int j = 15; j >= 0; --j) {
+      const uint32_t q = out[j];
+      uint32_t e = q;
+      if (q >= NXT_STOP)
+        e = 16 * tid + j;
+      else if (q < block_end)
+        e = exitp[q];
+      exitp[16 * tid + j] = (uint16_t)e;
+    }
+    entry_of[tid] = 0xFFFFu;
   }
   __syncthreads();
-  // ---- B. the chain from the stream position
+  // ---- B2. the chain from the stream position, block by block
   if (tid == 0) {
-    uint32_t n = 0, p = entry, stop = NXT_STOP;
-    while (p < (uint32_t)PLAN_WINDOW && n < (uint32_t)PLAN_WINDOW) {
-      const uint32_t q = nxt[p];
-      if (q >= NXT_STOP) {
-        stop = q;
+    uint32_t p = entry, stop = NXT_STOP;
+    while (p < (uint32_t)PLAN_WINDOW) {
+      const uint32_t blk = p >> 4;
+      entry_of[blk] = (uint16_t)p;
+      const uint32_t e = exitp[p];
+      if (e < 16 * blk + 16) {  // the chain stops inside this block
+        p = e;
+        stop = nxt[e];
         break;
       }
-      list[n++] = (uint16_t)p;
-      p = q;
+      p = e;
     }
-    st.list_n = n;
     st.list_after = p;     // window offset behind the last run listed
     st.list_stop = stop;   // NXT_COMPLEX: the run at list_after is for the serial walk
+  }
+  __syncthreads();
+  // ---- B3. the runs of every block the chain visits, then all of them in stream order
+  {
+    uint16_t* mine = exitp + 16 * tid;  // B2 is done with this block's exits
+    uint32_t c = 0, p = entry_of[tid];
+    while (p < block_end) {  // 0xFFFF: the chain does not come through here
+      const uint32_t q = nxt[p];
+      if (q >= NXT_STOP) break;
+      mine[c++] = (uint16_t)p;
+      p = q;
+    }
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(inc, off, 64);
+      if (tid >= (uint32_t)off) inc += up;
+    }
+    for (uint32_t i = 0; i < c; ++i) list[inc - c + i] = mine[i];
+    if (tid == PLAN_THREADS - 1) st.list_n = inc;
   }
   __syncthreads();
   // ---- C. segments, 64 runs at a time
@@ -460,6 +502,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   __shared__ RleSeg chunk[SEG_CHUNK];
   __shared__ u32x4 nxt4[PLAN_WINDOW / 8], list4[PLAN_WINDOW / 8];
   __shared__ PlanState st;
+  __shared__ uint16_t entry_of[PLAN_THREADS];
   uint16_t* nxt = reinterpret_cast<uint16_t*>(nxt4);
   uint16_t* list = reinterpret_cast<uint16_t*>(list4);
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
@@ -748,7 +791,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
     }
     // a fresh contiguous window is planned by all lanes; the serial walk takes only what that leaves
     const bool windowed = fresh && st.round_stride == 16 && st.pending == 0 && !st.done && st.nstage < (uint32_t)SEG_GEN_MAX;
-    if (windowed) plan_window(st, win4, nxt, list, stage, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
+    if (windowed)
+      plan_window(st, win4, nxt, list, reinterpret_cast<uint16_t*>(chunk), entry_of, stage, end, w, n_values, (uint32_t)SEG_GEN_MAX, tid);
     if (tid == 0 && !st.need_round && !st.done)
       plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_GEN_MAX, windowed ? 1u : ~0u);
     __syncthreads();
