@@ -212,16 +212,17 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
 // `run_stride` stream bytes, one behind the other (the plan kernel's bulk path marks such chunks).
 // The run of a unit follows from its index, so there is no table, no search and no LDS traffic:
 // a division by the (wave-uniform) run length, one load, the extracts, one store.
-template <bool WIDE>
+template <bool WIDE, int VPU>  // VPU: values per unit, 4, or 8 for widths up to 8 bits
 __device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t start0, uint32_t src0, uint32_t run_values,
                                                     uint32_t run_stride, float rcp_values, uint32_t t0, uint32_t v1,
                                                     PQD_GLOBAL uint32_t* out, uint32_t tid) {
+  static_assert(VPU == 4 || (VPU == 8 && !WIDE), "eight values per unit only where they fit 64 bits");
   constexpr int NW = WIDE ? 5 : 3;
   const uint32_t max_wi = h.last_word + 1 - NW;  // a regular run is at least 24 bytes: the page holds a unit load
   uint32_t wi[EX_UNITS], sh[EX_UNITS], delta[EX_UNITS];
 #pragma unroll
   for (int k = 0; k < EX_UNITS; ++k) {
-    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    const uint32_t g0 = t0 + VPU * ((uint32_t)k * EX_THREADS + tid);
     const uint32_t rel = (g0 < v1 ? g0 : t0) - start0;  // below 2^17: exact as a float
     uint32_t q = (uint32_t)((float)rel * rcp_values);
     q -= q * run_values > rel ? 1u : 0u;
@@ -253,7 +254,7 @@ __device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t st
   const uint32_t mask = mask32(h.w);
 #pragma unroll
   for (int k = 0; k < EX_UNITS; ++k) {
-    const uint32_t g0 = t0 + 4 * ((uint32_t)k * EX_THREADS + tid);
+    const uint32_t g0 = t0 + VPU * ((uint32_t)k * EX_THREADS + tid);
     if (delta[k]) {  // rare
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
@@ -263,27 +264,28 @@ __device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t st
         d[k][j] = x;
       }
     }
-    uint32_t a0, a1, a2, a3;
+    uint32_t a[VPU];
     if (WIDE) {
       Window5 wnd = {d[k][0], d[k][1], d[k][2], d[k][WIDE ? 3 : 0], d[k][WIDE ? 4 : 0]};
       wnd.shr(sh[k]);
-      a0 = wnd.d0 & mask;
+      a[0] = wnd.d0 & mask;
       wnd.drop(h.w);
-      a1 = wnd.d0 & mask;
+      a[1] = wnd.d0 & mask;
       wnd.drop(h.w);
-      a2 = wnd.d0 & mask;
+      a[2] = wnd.d0 & mask;
       wnd.drop(h.w);
-      a3 = wnd.d0 & mask;
+      a[3] = wnd.d0 & mask;
     } else {
       const uint32_t lo = funnel_shr(d[k][0], d[k][1], sh[k]), hi = funnel_shr(d[k][1], d[k][2], sh[k]);
-      a0 = ex_unit_value(lo, hi, h.w, 0);
-      a1 = ex_unit_value(lo, hi, h.w, 1);
-      a2 = ex_unit_value(lo, hi, h.w, 2);
-      a3 = ex_unit_value(lo, hi, h.w, 3);
+#pragma unroll
+      for (int j = 0; j < VPU; ++j) a[j] = ex_unit_value(lo, hi, h.w, (uint32_t)j);
     }
     if (g0 < v1) {  // v1 of a regular chunk is a multiple of SEG_BLOCK: whole units only
-      const u32x4_a4 r4 = {a0, a1, a2, a3};
-      *(PQD_GLOBAL u32x4_a4*)(out + g0) = r4;
+#pragma unroll
+      for (int j = 0; j < VPU; j += 4) {
+        const u32x4_a4 r4 = {a[j], a[j + 1], a[j + 2], a[j + 3]};
+        *(PQD_GLOBAL u32x4_a4*)(out + g0 + j) = r4;
+      }
     }
   }
 }
@@ -325,12 +327,13 @@ __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restr
       const uint32_t run_stride = uni(hd->reserved[1]);
       const uint32_t start0 = uni(cs[0].start4) >> 2, src0 = uni(cs[0].src);
       const float rcp_values = 1.0f / (float)run_values;
+      // (units of eight values for narrow widths were measured: slower, the stores coalesce worse)
       if (h.w <= 16) {
         for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE)
-          expand_regular_tile<false>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
+          expand_regular_tile<false, 4>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
       } else {
         for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE)
-          expand_regular_tile<true>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
+          expand_regular_tile<true, 4>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
       }
     } else if (h.w <= 16) {
       for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<false>(cs, h, v0, t0, v1, out, tid, wave);
