@@ -13,6 +13,7 @@ def main():
     pq.init(0)
     stream = torch.cuda.current_stream().cuda_stream
     pages = 5000
+    bench.DICT_ENTRIES = int(os.environ.get("DBG_ENTRIES", bench.DICT_ENTRIES))  # smaller: the dictionary stays in LDS
     for elem in (4, 8):
         blob, page_len, ids, dictionary, out = bench.build_column(pages, elem, 1, dev)
         d_descs, d_res = bench.make_descs(blob, page_len, dictionary, out, elem, dev)

@@ -97,6 +97,13 @@ def main():
     page = len(body).to_bytes(4, "little") + bytes(body)
     run_pages("definition levels w=2 (V1 prefix), 5000 pages x 20000", [page], 5000, 20000, pq.ENC_RLE, 4, bit_width=2,
               flags=pq.F_LENGTH_PREFIX if hasattr(pq, "F_LENGTH_PREFIX") else 1)
+    # dictionary pages whose dictionary fits LDS whole (4096 entries, id width 12), and the 64 Ki-entry ones
+    for elem, dt in ((4, np.int32), (8, np.int64)):
+        for entries in (4096, 65536):
+            dic = rng.integers(-(1 << 31), 1 << 31, entries).astype(dt)
+            ps = [orc.dict_encode_ids(rng.integers(0, entries, 20000).astype(np.int32), entries) for _ in range(4)]
+            run_pages(f"dictionary INT{elem * 8}, {entries} entries, 5000 pages x 20000", ps, 1250, 20000,
+                      pq.ENC_RLE_DICTIONARY, elem, dictionary=dic)
     # delta binary packed timestamps
     for k in (12, 40):
         ts = 1_600_000_000_000_000_000 + np.cumsum(1000 + rng.integers(0, 1 << k, 20000)).astype(np.int64)
