@@ -49,6 +49,8 @@ struct DeltaState {
   uint32_t fast_blocks;   // whole blocks found by the quick walk in the current window ...
   uint32_t fast_take;     // ... and the miniblocks of the last of them (the others have mini_n)
   uint32_t fast_base;     // table index of their first miniblock
+  uint32_t spec_blocks;   // whole blocks found by wave 0 at the start of the current window ...
+  uint32_t spec_bytes;    // ... and the stream bytes they take
 };
 
 __device__ __forceinline__ bool lds_varint(lds_words_t win, int32_t base, uint32_t& p, uint32_t end,
@@ -79,10 +81,21 @@ __device__ __forceinline__ int64_t zigzag64(uint64_t raw) {  // BytesUtils.java:
 // Reads the 16 bytes at window offset `off`, where a block header starts: the length of the
 // min-delta varint from its continuation bits (`nbv`, 1..8) and the sum of the first `take` width
 // bytes behind it (`wsum`).  False if the varint is longer than 8 bytes or a width exceeds 64.
+// UNIFORM: the caller is a single lane (or all lanes with the same `off`); the dwords are moved to
+// scalar registers so that the bit work runs on the scalar unit, whose dependent operations issue
+// back to back (the serial block walk is a chain of these).
+template <bool UNIFORM = false>
 __device__ __forceinline__ bool quick_block(lds_words_t win, uint32_t off, uint32_t mn, uint32_t take, uint32_t& nbv,
                                             uint32_t& wsum) {
   const uint32_t i0 = off >> 2, sh = (off & 3u) * 8u;
-  const uint32_t a0 = win[i0], a1 = win[i0 + 1], a2 = win[i0 + 2], a3 = win[i0 + 3], a4 = win[i0 + 4];
+  uint32_t a0 = win[i0], a1 = win[i0 + 1], a2 = win[i0 + 2], a3 = win[i0 + 3], a4 = win[i0 + 4];
+  if (UNIFORM) {
+    a0 = __builtin_amdgcn_readfirstlane(a0);
+    a1 = __builtin_amdgcn_readfirstlane(a1);
+    a2 = __builtin_amdgcn_readfirstlane(a2);
+    a3 = __builtin_amdgcn_readfirstlane(a3);
+    a4 = __builtin_amdgcn_readfirstlane(a4);
+  }
   const uint32_t b0 = funnel_shr(a0, a1, sh), b1 = funnel_shr(a1, a2, sh), b2 = funnel_shr(a2, a3, sh), b3 = funnel_shr(a3, a4, sh);
   const uint64_t lo = ((uint64_t)b1 << 32) | b0, hi = ((uint64_t)b3 << 32) | b2;
   const uint64_t stop = ~lo & 0x8080808080808080ull;  // bytes without the continuation bit
@@ -106,7 +119,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   __shared__ uint8_t cur_widths[MAX_MINI_PER_BLOCK];
   __shared__ acc_t wave_sum[DELTA_THREADS / 64];
   __shared__ uint32_t blk_off[MAX_FAST_BLOCKS];  // window offset of the block headers found by the quick walk
-  __shared__ uint32_t spec_first_no[DELTA_THREADS / 64];
   __shared__ DeltaState st;
   lds_words_t win = (lds_words_t)(const PQD_LDS u32x4*)win4;
 
@@ -194,37 +206,48 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       __syncthreads();
     }
     // ---- 2. block-header walk (loadNewBlockToBuffer, :121-143; readBitWidthsForMiniBlocks, :164-172)
-    // 2a. All lanes at once, for the usual case of blocks of one length L (steady delta widths):
-    // lane t looks at offset t * L behind the first block and checks that a full block of that same
-    // length starts there.  The blocks up to the first lane that says no are taken as found.
-    uint32_t spec_m = 0, spec_L = 0;
-    {
+    // 2a. Wave 0, all lanes at once, for stretches of blocks of one length L (steady delta widths):
+    // lane t looks at offset t * L behind the stretch's first block and checks that a full block of
+    // that same length starts there.  The blocks up to the first lane that says no are taken as
+    // found; the next stretch starts at that block, with its length.  The walk ends where a block
+    // is not wholly wanted, does not fit the window or does not pass the quick checks: lane 0
+    // carries on from there below.
+    uint32_t spec_m = 0, spec_bytes = 0;
+    if (tid < 64) {
       const int32_t base = first_window ? st.window_base : wbase;
       const uint32_t wend = (uint32_t)(base + DWINDOW_BYTES);
-      const uint32_t p = st.pos, mn = st.mini_n, scanned = st.deltas_done;
+      const uint32_t mn = st.mini_n, bs = st.block_size;
+      uint32_t p = st.pos, scanned = st.deltas_done, found = 0;
       const bool can = st.minis_left == 0 && mn <= 8 && mn > 0;
-      bool ok = false;
-      if (can && p + 16 <= end && p + 16 <= wend) {
+      while (can && found < (uint32_t)MAX_FAST_BLOCKS && p + 16 <= end && p + 16 <= wend) {
         uint32_t nbv0, wsum0;
-        const bool ok0 = quick_block(win, (uint32_t)(p - base), mn, mn, nbv0, wsum0);
-        spec_L = nbv0 + mn + (mini_size >> 3) * wsum0;
-        const uint64_t pt = (uint64_t)p + (uint64_t)tid * spec_L;
-        if (ok0 && pt + 16 <= end && pt + 16 <= wend && pt + spec_L <= end && pt + spec_L <= wend &&
-            (uint64_t)scanned + (uint64_t)(tid + 1) * st.block_size <= n_deltas && (tid + 1) * mn <= (uint32_t)MAX_MINIS) {
+        const bool ok0 = quick_block<true>(win, (uint32_t)(p - base), mn, mn, nbv0, wsum0);
+        const uint32_t L = nbv0 + mn + (mini_size >> 3) * wsum0;
+        const uint64_t pt = (uint64_t)p + (uint64_t)tid * L;
+        bool ok = false;
+        if (ok0 && pt + 16 <= end && pt + 16 <= wend && pt + L <= end && pt + L <= wend &&
+            (uint64_t)scanned + (uint64_t)(tid + 1) * bs <= n_deltas && (found + tid + 1) * mn <= (uint32_t)MAX_MINIS &&
+            found + tid < (uint32_t)MAX_FAST_BLOCKS) {
           uint32_t nbv, wsum;
           const uint32_t off = (uint32_t)(pt - base);
-          ok = quick_block(win, off, mn, mn, nbv, wsum) && nbv + mn + (mini_size >> 3) * wsum == spec_L;
-          if (ok) blk_off[tid] = off;  // entries past the first refusal are ignored
+          ok = quick_block(win, off, mn, mn, nbv, wsum) && nbv + mn + (mini_size >> 3) * wsum == L;
+          if (ok) blk_off[found + tid] = off;  // entries past the first refusal are overwritten or ignored
         }
+        const uint64_t no = ~__builtin_amdgcn_ballot_w64(ok);
+        const uint32_t m = no ? (uint32_t)__builtin_ctzll(no) : 64u;
+        if (m == 0) break;
+        found += m;
+        p += m * L;
+        scanned += m * bs;
       }
-      const uint64_t no = ~__builtin_amdgcn_ballot_w64(ok);
-      if ((tid & 63u) == 0) spec_first_no[tid >> 6] = (tid & ~63u) + (no ? (uint32_t)__builtin_ctzll(no) : 64u);
-      __syncthreads();
-      spec_m = DELTA_THREADS;
-#pragma unroll
-      for (int k = DELTA_THREADS / 64 - 1; k >= 0; --k)
-        if (spec_first_no[k] < (uint32_t)(k + 1) * 64u) spec_m = spec_first_no[k];
+      if (tid == 0) {
+        st.spec_blocks = found;
+        st.spec_bytes = p - st.pos;
+      }
     }
+    __syncthreads();
+    spec_m = st.spec_blocks;
+    spec_bytes = st.spec_bytes;
     if (tid == 0) {
       const int32_t base = first_window ? st.window_base : wbase;
       st.window_base = base;
@@ -294,8 +317,14 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
         // the blocks found by all lanes above
         nblk = spec_m;
         nm += spec_m * mn;
-        p += spec_m * spec_L;
+        p += spec_bytes;
         scanned += spec_m * st.block_size;
+        p = __builtin_amdgcn_readfirstlane(p);
+        nm = __builtin_amdgcn_readfirstlane(nm);
+        scanned = __builtin_amdgcn_readfirstlane(scanned);
+        nblk = __builtin_amdgcn_readfirstlane(nblk);
+        // miniblocks still wanted (one division here instead of one per block)
+        uint32_t left_minis = __builtin_amdgcn_readfirstlane((n_deltas - scanned + mini_size - 1) / mini_size);
         while (nm + mn <= MAX_MINIS && nblk < (uint32_t)MAX_FAST_BLOCKS && scanned < n_deltas) {
           if (p + 16 > end) break;
           if (p + 16 > wend) {
@@ -303,10 +332,9 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
             break;
           }
           const uint32_t off = (uint32_t)(p - base);
-          const uint32_t left_minis = (n_deltas - scanned + mini_size - 1) / mini_size;
           const uint32_t take = left_minis < mn ? left_minis : mn;
           uint32_t nbv, wsum;
-          if (!quick_block(win, off, mn, take, nbv, wsum)) break;
+          if (!quick_block<true>(win, off, mn, take, nbv, wsum)) break;
           const uint32_t pay = p + nbv + mn, bytes = mini_bytes_unit * wsum;
           if (end - pay < bytes) break;
           if (pay + bytes > wend) {
@@ -319,6 +347,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
           nm += take;
           p = pay + bytes;
           scanned += take * mini_size;
+          left_minis -= take;
         }
       }
       st.fast_blocks = nblk;
