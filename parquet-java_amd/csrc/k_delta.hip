@@ -183,6 +183,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   const uint32_t total = st.total;
   const uint32_t mini_size = st.mini_size;
   const uint32_t n_deltas = total > 0 ? total - 1 : 0;
+  // miniblocks of 2^k values (the writers' 32): a shift instead of a division per lane and tile
+  const uint32_t mini_shift = (mini_size & (mini_size - 1)) == 0 && mini_size ? (uint32_t)__builtin_ctz(mini_size) : ~0u;
   acc_t carry = (acc_t)st.first;  // value at output index deltas_done
   acc_t* out = reinterpret_cast<acc_t*>(d.out);
   bool first_window = true;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       acc_t dv[4] = {0, 0, 0, 0};
       acc_t mn = 0;
       if (l < wd) {
-        const uint32_t m = l / mini_size;
+        const uint32_t m = mini_shift != ~0u ? l >> mini_shift : l / mini_size;
         const uint32_t w = mini_w[m];
         mn = (acc_t)mini_min[m];
         uint32_t bit = mini_src[m] * 8 + (l - m * mini_size) * w;
@@ -444,20 +446,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       }
       const acc_t s = (acc_t)(mn * 4 + dv[0] + dv[1] + dv[2] + dv[3]);
       // inclusive scan over the wave
-      acc_t inc = s;
+      const acc_t inc = wave_scan_inclusive(s);
       const uint32_t lane = tid & 63u;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        acc_t up;
-        if (ELEM == 8) {
-          uint32_t lo32 = __shfl_up((uint32_t)inc, off, 64);
-          uint32_t hi32 = __shfl_up((uint32_t)((uint64_t)inc >> 32), off, 64);
-          up = (acc_t)(((uint64_t)hi32 << 32) | lo32);
-        } else {
-          up = (acc_t)__shfl_up((uint32_t)inc, off, 64);
-        }
-        if (lane >= (uint32_t)off) inc += up;
-      }
       if (lane == 63) wave_sum[tid >> 6] = inc;
       __syncthreads();
       acc_t before = 0, tile_total = 0;

@@ -96,6 +96,34 @@ __device__ __forceinline__ void stage_window(u32x4* lds, const uint8_t* gbase, c
   }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS traffic): four shifts
+// inside the rows of 16 lanes, then the row totals are passed on with the two row broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
+  v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_scan_inclusive(uint64_t v) {
+#define PQD_SCAN_STEP64(CTRL, MASK)                                                                     \
+  v += ((uint64_t)dpp_or_zero<CTRL, MASK>((uint32_t)(v >> 32)) << 32) | dpp_or_zero<CTRL, MASK>((uint32_t)v);
+  PQD_SCAN_STEP64(0x111, 0xF)
+  PQD_SCAN_STEP64(0x112, 0xF)
+  PQD_SCAN_STEP64(0x114, 0xF)
+  PQD_SCAN_STEP64(0x118, 0xF)
+  PQD_SCAN_STEP64(0x142, 0xA)
+  PQD_SCAN_STEP64(0x143, 0xC)
+#undef PQD_SCAN_STEP64
+  return v;
+}
+
 __device__ __forceinline__ uint32_t lds_byte(const uint32_t* lds_words, uint32_t off) {
   return (lds_words[off >> 2] >> ((off & 3u) * 8u)) & 0xFFu;
 }
