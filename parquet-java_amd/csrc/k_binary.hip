@@ -111,12 +111,7 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     uint64_t lane_total = 0;
 #pragma unroll
     for (int j = 0; j < BN_VPL; ++j) lane_total += len[j];
-    uint64_t inc = lane_total;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const uint64_t o = shfl_up64(inc, s);
-      if (lane >= (uint32_t)s) inc += o;
-    }
+    const uint64_t inc = wave_scan_inclusive(lane_total);
     if (lane == 63) wave_total[wave] = inc;
     __syncthreads();
     uint64_t lane_base = inc - lane_total, tile_total = 0;
