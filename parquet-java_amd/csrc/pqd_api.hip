@@ -71,14 +71,13 @@ int check_device_available() {
   return PQD_OK;
 }
 
-// Device scratch of the planned RLE path: one run-plan record and one segment chunk per page.
+// Device scratch of the planned RLE paths: one run-plan record per page and the chunk pool.
 // One per (device, stream): calls on one stream are ordered, calls on different streams must not
 // share it.  Grown on demand, never shrunk, released with the process.
 struct PlanScratch {
   void* plans = nullptr;
-  void* pool = nullptr;        // dictionary path: chunk p belongs to page p
   uint32_t cap_pages = 0;
-  void* gen_pool = nullptr;    // plain hybrid pages: chunks handed out through counters[0]
+  void* gen_pool = nullptr;    // chunk pool: chunk p for page p, the rest handed out through counters[0]
   uint32_t gen_chunks = 0;
   uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool
 };
@@ -94,12 +93,10 @@ int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
     // wait for work that may still use the old buffers, then replace them
     PQD_HIP(hipStreamSynchronize(stream));
     if (ps.plans) (void)hipFree(ps.plans);
-    if (ps.pool) (void)hipFree(ps.pool);
-    ps.plans = ps.pool = nullptr;
+    ps.plans = nullptr;
     ps.cap_pages = 0;
     const uint32_t pages = n_pages + n_pages / 4 + 64;
     PQD_HIP(hipMalloc(&ps.plans, (size_t)pages * sizeof(pqd::RlePagePlan)));
-    PQD_HIP(hipMalloc(&ps.pool, (size_t)pages * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
     ps.cap_pages = pages;
   }
   *out = ps;
@@ -171,6 +168,16 @@ int phase_mark(int i, hipStream_t s) {
 bool use_sliced_dictionary_path() {
   const char* v = getenv("PQD_DICT_PATH");
   return !(v && strcmp(v, "generic") == 0);
+}
+
+// Chunks of the pool the kernels may use: all of them, unless PQD_POOL_CHUNKS sets a lower bound
+// (pages that find no room are decoded by the generic kernel; the tests use it to reach that path
+// without gigabyte pages).
+uint32_t usable_pool_chunks(uint32_t have) {
+  const char* v = getenv("PQD_POOL_CHUNKS");
+  if (!v) return have;
+  const long lim = atol(v);
+  return lim < 0 ? 0u : ((unsigned long)lim < have ? (uint32_t)lim : have);
 }
 
 // The same switch for plain hybrid pages: PQD_RLE_PATH=generic selects the single generic kernel.
@@ -409,9 +416,10 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         PlanScratch ps;
         int st = plan_scratch_general(s, n_pages, &ps);
         if (st) return st;
+        const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, false, 4, s));
-        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, s));
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4, s));
+        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, ps.counters, n_pages, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, ps.counters + 1, s));
       }
       return PQD_OK;
@@ -428,10 +436,11 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if (st) return st;
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
         if ((st = phase_mark(0, s))) return st;
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, true,
+        const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, true,
                                             elem_size, s));
         if ((st = phase_mark(1, s))) return st;
-        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, ps.gen_chunks, ps.counters, n_pages, elem_size, s));
+        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, s));
         if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s));
         if ((st = phase_mark(3, s))) return st;

@@ -571,3 +571,32 @@ def test_dictionary_long_regular_pages(gpu, orc, elem, dict_path):
     for (st, written, _, out, guard), (ost, ovals) in zip(gpu.decode_pages(pages), expect):
         assert st == ost == 0 and written == ovals.size
         assert (out.view(ovals.dtype) == ovals).all() and (guard == 0xA5).all()
+
+
+@pytest.mark.parametrize("limit", [0, 3, 7, 12, 40])
+def test_pages_that_find_the_chunk_pool_full(gpu, orc, monkeypatch, limit):
+    """With fewer pool chunks than the pages need (PQD_POOL_CHUNKS), the pages that find no room
+    are decoded by the generic kernel; results do not change.  Long regular pages ask for many
+    chunks at once (bulk path), irregular ones chunk by chunk."""
+    import parquet_java_amd as pq
+    monkeypatch.setenv("PQD_POOL_CHUNKS", str(limit))
+    monkeypatch.setenv("PQD_RLE_PATH", "planned")
+    monkeypatch.setenv("PQD_DICT_PATH", "sliced")
+    rng = np.random.default_rng(91 + limit)
+    cases = []
+    for w, n in ((8, 300_000), (3, 70_000), (12, 5000), (16, 131_072)):
+        cases.append((w, orc.rle_encode(w, rand_vals(rng, w, n)), n, 0))
+    runs = np.repeat(rng.integers(0, 16, 6000), rng.geometric(1 / 30.0, 6000))[:150_000].astype(np.int32)
+    cases.append((4, orc.rle_encode(4, runs), runs.size, 0))
+    cases.append((5, orc.rle_encode(5, rand_vals(rng, 5, 100)), 100, 0))
+    check_rle(gpu, orc, cases)
+    for elem, dt in ((4, np.int32), (8, np.int64)):
+        dic = rng.integers(-(1 << 31), 1 << 31, 1 << 10).astype(dt)
+        pages, expect = [], []
+        for n in (100_000, 20_000, 50, 45_000):
+            ids = rng.integers(0, dic.size, n).astype(np.int32)
+            data = orc.dict_encode_ids(ids, dic.size)
+            pages.append(gpu.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            expect.append(dic[ids])
+        for (st, written, _, out, guard), exp in zip(gpu.decode_pages(pages), expect):
+            assert st == 0 and written == exp.size and (out.view(dt) == exp).all() and (guard == 0xA5).all()
