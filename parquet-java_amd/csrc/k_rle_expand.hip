@@ -52,9 +52,14 @@ constexpr uint32_t EK_NONE = 0, EK_PACKED = 1, EK_RLE = 2, EK_SLOW = 3;
 
 // One tile of EX_TILE values starting at output index t0 (a multiple of SEG_BLOCK past v0).
 // WIDE: ids of 17..32 bits (five dwords per unit) instead of up to 16 bits (three).
+// Units that need the value-by-value treatment (run boundaries off multiples of four, truncated
+// runs, the page's last dwords) are not done by their lane: they are put on a list in LDS and the
+// whole workgroup then does them one VALUE per lane, so that a wave with one such unit among its 64
+// does not walk all its lanes through that path.
 template <bool WIDE>
 __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHead& h, uint32_t v0, uint32_t t0,
-                                            uint32_t v1, PQD_GLOBAL uint32_t* out, uint32_t tid, uint32_t wave) {
+                                            uint32_t v1, PQD_GLOBAL uint32_t* out, uint32_t tid, uint32_t wave,
+                                            uint32_t* slow_list, uint32_t* slow_n, uint32_t parity) {
   constexpr int NW = WIDE ? 5 : 3;
   const PQD_LDS uint8_t* table = (const PQD_LDS uint8_t*)(cs + SEG_TABLE_SLOT);
   const uint32_t v1x4 = v1 << 2;
@@ -162,42 +167,11 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
       a3 = ex_unit_value(lo, hi, h.w, 3);
     }
     if (kind != EK_PACKED) a0 = a1 = a2 = a3 = other[k];
-    if (kind == EK_SLOW) {  // run boundaries off multiples of four, truncated runs, the page's last dwords
-      // value by value, but with the eight loads of the unit in flight together
-      uint32_t t = meta[k] >> 16;
-      uint32_t wj[4], shj[4], vj[4];
-      bool pk[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t g = g0 + j < v1 ? g0 + j : v1 - 1;  // values past the end repeat the last one (not stored)
-        while (cs[t + 1].start4 <= g * 4 + 3) ++t;          // stops at the sentinel (start == v1 > g)
-        const uint32_t tk = cs[t].start4, src = cs[t].src;
-        const uint32_t byte0 = h.in_off + src;
-        const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
-        pk[j] = (tk & SEG_PACKED_BIT) != 0;
-        wj[j] = pk[j] ? (byte0 >> 2) + (bitrel >> 5) : 0u;
-        shj[j] = bitrel & 31u;
-        vj[j] = src;
-      }
-      uint32_t x0[4], x1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // clamped addresses: never past the page
-        x0[j] = h.words[wj[j] < h.last_word ? wj[j] : h.last_word];
-        x1[j] = h.words[wj[j] + 1 < h.last_word ? wj[j] + 1 : h.last_word];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // bytes at or past the end of the stream read as zero
-        const uint32_t i0 = wj[j], i1 = wj[j] + 1;
-        const uint32_t y0 = i0 < h.full_words ? x0[j] : (i0 == h.full_words ? x0[j] & h.tail_mask : 0u);
-        const uint32_t y1 = i1 < h.full_words ? x1[j] : (i1 == h.full_words ? x1[j] & h.tail_mask : 0u);
-        vj[j] = pk[j] ? funnel_shr(y0, y1, shj[j]) & mask : vj[j];
-      }
-      a0 = vj[0];
-      a1 = vj[1];
-      a2 = vj[2];
-      a3 = vj[3];
-    }
-    if (g0 + 4 <= v1) {
+    if (kind == EK_SLOW) {
+      const uint32_t idx = atomicAdd(&slow_n[parity], 1u);
+      slow_list[2 * idx] = g0;
+      slow_list[2 * idx + 1] = meta[k] >> 16;  // the segment of the unit's first value
+    } else if (g0 + 4 <= v1) {
       const u32x4_a4 r4 = {a0, a1, a2, a3};
       *(PQD_GLOBAL u32x4_a4*)(out + g0) = r4;
     } else if (g0 < v1) {
@@ -206,6 +180,29 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
       if (g0 + 2 < v1) out[g0 + 2] = a2;
     }
   }
+  __syncthreads();
+  const uint32_t n_slow = slow_n[parity];
+  if (tid == 0) slow_n[parity ^ 1u] = 0;  // the next tile's counter (this one is read until the barrier below)
+  for (uint32_t i = tid; i < 4 * n_slow; i += EX_THREADS) {
+    const uint32_t g = slow_list[2 * (i >> 2)] + (i & 3u);
+    uint32_t t = slow_list[2 * (i >> 2) + 1];
+    if (g >= v1) continue;
+    while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
+    const uint32_t tk = cs[t].start4, src = cs[t].src;
+    uint32_t v = src;  // the repeated value of an RLE run
+    if (tk & SEG_PACKED_BIT) {
+      const uint32_t byte0 = h.in_off + src;
+      const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
+      const uint32_t i0 = (byte0 >> 2) + (bitrel >> 5), i1 = i0 + 1;
+      // clamped addresses: never past the page; bytes at or past the end of the stream read as zero
+      const uint32_t x0 = h.words[i0 < h.last_word ? i0 : h.last_word], x1 = h.words[i1 < h.last_word ? i1 : h.last_word];
+      const uint32_t y0 = i0 < h.full_words ? x0 : (i0 == h.full_words ? x0 & h.tail_mask : 0u);
+      const uint32_t y1 = i1 < h.full_words ? x1 : (i1 == h.full_words ? x1 & h.tail_mask : 0u);
+      v = funnel_shr(y0, y1, bitrel & 31u) & mask;
+    }
+    out[g] = v;
+  }
+  __syncthreads();
 }
 
 // One tile of a REGULAR chunk: every segment is a whole bit-packed run of `run_values` values and
@@ -293,6 +290,8 @@ __device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t st
 __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                            const uint32_t* __restrict__ cursor, uint32_t n_pages) {
   __shared__ RleSeg cs_buf[SEG_CHUNK];
+  __shared__ uint32_t slow_list[2 * EX_THREADS * EX_UNITS];  // {first value, segment} of the units left to the value-by-value pass
+  __shared__ uint32_t slow_n[2];                              // their number, one counter per tile parity
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = uni(tid >> 6);
   // chunks to take: one per page (empty ones included) and the extra ones the plan kernel took from
@@ -300,6 +299,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restr
   uint32_t n_chunks = n_pages + uni(*cursor);
   if (n_chunks > pool_chunks) n_chunks = pool_chunks;
   const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)cs_buf;
+  uint32_t parity = 0;
+  if (tid < 2) slow_n[tid] = 0;  // (the first barrier of the chunk loop comes before any use)
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     __syncthreads();  // everybody is done with the previous chunk
     {
@@ -336,9 +337,11 @@ __global__ __launch_bounds__(EX_THREADS) void k_rle_expand(const RleSeg* __restr
           expand_regular_tile<true, 4>(h, start0, src0, run_values, run_stride, rcp_values, t0, v1, out, tid);
       }
     } else if (h.w <= 16) {
-      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<false>(cs, h, v0, t0, v1, out, tid, wave);
+      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE, parity ^= 1u)
+        expand_tile<false>(cs, h, v0, t0, v1, out, tid, wave, slow_list, slow_n, parity);
     } else {
-      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE) expand_tile<true>(cs, h, v0, t0, v1, out, tid, wave);
+      for (uint32_t t0 = v0; t0 < v1; t0 += EX_TILE, parity ^= 1u)
+        expand_tile<true>(cs, h, v0, t0, v1, out, tid, wave, slow_list, slow_n, parity);
     }
   }
 }

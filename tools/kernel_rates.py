@@ -97,6 +97,16 @@ def main():
     page = len(body).to_bytes(4, "little") + bytes(body)
     run_pages("definition levels w=2 (V1 prefix), 5000 pages x 20000", [page], 5000, 20000, pq.ENC_RLE, 4, bit_width=2,
               flags=pq.F_LENGTH_PREFIX if hasattr(pq, "F_LENGTH_PREFIX") else 1)
+    # nested levels of a 3-deep optional schema with 10 % nulls per level, lists of ~Geometric(3) elements
+    u = rng.random((3, 20000))
+    dl = (u[0] >= 0.1).astype(np.int32) * (1 + (u[1] >= 0.1) * (1 + (u[2] >= 0.1)))
+    body = orc.rle_encode(2, dl.astype(np.int32))
+    run_pages("definition levels, max 3, 10% nulls per level, 5000 x 20000", [len(body).to_bytes(4, "little") + bytes(body)], 5000,
+              20000, pq.ENC_RLE, 4, bit_width=2, flags=1)
+    rl = (rng.random(20000) >= 1 / 3.0).astype(np.int32)
+    body = orc.rle_encode(1, rl)
+    run_pages("repetition levels, max 1, lists ~Geometric(3), 5000 x 20000", [len(body).to_bytes(4, "little") + bytes(body)], 5000,
+              20000, pq.ENC_RLE, 4, bit_width=1, flags=1)
     # dictionary pages whose dictionary fits LDS whole (4096 entries, id width 12), and the 64 Ki-entry ones
     for elem, dt in ((4, np.int32), (8, np.int64)):
         for entries in (4096, 65536):
