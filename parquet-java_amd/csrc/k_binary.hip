@@ -29,11 +29,6 @@ constexpr uint32_t BN_NONE = 0xFFFFFFFFu;
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint64_t u64_a8 __attribute__((aligned(8)));
 
-__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d) {
-  const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // ORs `count` (1..16) bytes held in `v` (little-endian, bytes past count are ignored) into the
 // zeroed window at byte position `dst`.
 __device__ __forceinline__ void or_bytes(uint32_t* win, uint32_t dst, u32x4 v, uint32_t count) {

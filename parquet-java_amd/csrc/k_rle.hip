@@ -418,7 +418,7 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
 
 // Without a plan array: workgroup b decodes page b.  With one: only the pages the planned path could
 // not take are decoded here; the plan kernel has listed them (entry i of the list sits in
-// only_fallback[i].reserved, their number in *fallback_count), and a small grid strides over the list.
+// only_fallback[i].fallback_page, their number in *fallback_count), and a small grid strides over the list.
 template <int ELEM, bool HAS_DICT>
 __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
                                                            pqd_page_result* __restrict__ results,
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
   uint32_t n = *fallback_count;
   if (n > n_pages) n = n_pages;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t page = only_fallback[i].reserved;
+    const uint32_t page = only_fallback[i].fallback_page;
     if (page < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, page);
     __syncthreads();  // the next page reuses the LDS
   }

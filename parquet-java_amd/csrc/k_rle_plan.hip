@@ -580,7 +580,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   if (not_planned) {
     if (tid == 0) {
       plans[page].flags = PLAN_F_FALLBACK;
-      plans[atomicAdd(cursor + 1, 1u)].reserved = page;  // the generic kernel's work list
+      plans[atomicAdd(cursor + 1, 1u)].fallback_page = page;  // the generic kernel's work list
       if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page
   if (tid == 0) {
     if (emitted == 0 && page < pool_chunks) write_empty_chunk(pool, page);
     plans[page].flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
-    if (fallback) plans[atomicAdd(cursor + 1, 1u)].reserved = page;  // the generic kernel's work list
+    if (fallback) plans[atomicAdd(cursor + 1, 1u)].fallback_page = page;  // the generic kernel's work list
     if (!fallback) {
       pqd_page_result r;
       r.status = st.status;

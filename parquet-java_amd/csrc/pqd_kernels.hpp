@@ -14,16 +14,18 @@ hipError_t launch_unpack_run_i64(const uint8_t* in, uint64_t in_bytes, int64_t* 
                                  uint32_t w, hipStream_t stream);
 // elem: 4 or 8; has_dict: PQD_ENC_RLE_DICTIONARY pages
 // only_fallback_plans: nullptr = decode every page; else decode only pages whose plan is flagged for fallback
-// (the plan kernel lists those pages: entry i in plans[i].reserved, their number in *fallback_count)
+// (the plan kernel lists those pages: entry i in plans[i].fallback_page, their number in *fallback_count)
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
                             hipStream_t stream);
-// header walk -> run plans (pqd_rle_plan.hpp); `plans` holds n_pages records of 128 bytes, `pool`
-// pool_chunks chunks of 128 segments of 12 bytes, `pool_cursor` a zeroed counter
-// plain hybrid pages: header walk into pool chunks, then expansion of all chunks
+// header walk of hybrid pages (plain ones, or dictionary pages with want_dict) -> chunks of run
+// segments in `pool` (pqd_rle_plan.hpp): `plans` holds n_pages RlePagePlan records, `pool` pool_chunks
+// chunks, `cursor` two zeroed counters (chunks taken from the pool's shared tail; pages left to the
+// generic kernel)
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
                                   hipStream_t stream);
+// plain hybrid pages: expansion of all chunks
 hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather

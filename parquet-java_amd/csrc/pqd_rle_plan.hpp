@@ -1,5 +1,5 @@
 // Run plan of an RLE / bit-packing hybrid page: the output of the header-walk kernel
-// (k_rle_plan) and the input of the expansion kernels.
+// (k_rle_plan_chunks) and the input of the expansion kernels (k_rle_expand, k_dict_pages_sliced).
 //
 // The hybrid grammar is sequential (each run header sits right behind the previous run's
 // payload), so finding the runs is a pointer chase.  It is done once per page by a single wave,
@@ -22,24 +22,24 @@ constexpr uint32_t SEG_PACKED_BIT = 1u;   // bit-packed
 constexpr uint32_t SEG_PARTIAL_BIT = 2u;  // bit-packed and cut short by the end of the stream (missing bytes are zero)
 constexpr uint32_t SEG_START_MAX = 0x3FFFFFFFu;
 
-// The pool holds one chunk of SEG_CHUNK 8-byte slots per page:
-//   slots 0 .. nseg-1          the segments
-//   slot  nseg                 a sentinel whose start is n_out (so "start of the next segment" always exists)
-//   slots SEG_TABLE_SLOT ..    one byte per block of SEG_BLOCK output values: the segment that holds
-//                              the block's first value (a wave's unit row is one such block)
+// The plan of a page is a list of CHUNKS taken from a pool in device memory.  A chunk is SEG_CHUNK
+// 8-byte slots (2 KiB) and describes the output values [v0, v1) of one page: v0 and v1 are
+// multiples of SEG_BLOCK (v1 may also be the page's end), and
+//   slots 0 .. nseg-1          the segments; the first one may begin before v0
+//   slot  nseg                 a sentinel whose start is v1 (so "start of the next segment" always exists)
+//   slots SEG_HEAD_SLOT ..     the chunk's header (RleChunkHead): the consumers read nothing else of the page
+//   slots SEG_TABLE_SLOT ..    one byte per block of SEG_BLOCK output values: the segment that holds the
+//                              block's first value, block b starting at value v0 + b * SEG_BLOCK
+//                              (a wave's unit row is one such block)
+// Pool chunk p is reserved for page p (an empty chunk, v0 == v1, if the page yields nothing for the
+// consumer); a page's further chunks come from the shared tail of the pool through one counter.
 constexpr int SEG_CHUNK = 256;
 constexpr int SEG_TABLE_SLOT = 240;
-constexpr int SEG_MAX = SEG_TABLE_SLOT - 1;  // segments a planned page may have; beyond: generic kernel
 constexpr int SEG_BLOCK = 256;
 constexpr int SEG_TABLE_BLOCKS = (SEG_CHUNK - SEG_TABLE_SLOT) * 8;  // 128 blocks = 32768 values
 constexpr int PLAN_SEG_MAX_BYTES = 6144;  // payload bytes of one bit-packed segment
-
-// Plain hybrid pages (levels, ids, booleans) of any length are planned as a list of such chunks,
-// each covering the output values [v0, v1) of one page: v0 and v1 are multiples of SEG_BLOCK (v1
-// may also be the page's end), the first segment may begin before v0, the sentinel's start is v1,
-// table block b starts at value v0 + b * SEG_BLOCK, and the chunk carries its own header:
 constexpr int SEG_HEAD_SLOT = 232;               // slots 232..239: RleChunkHead
-constexpr int SEG_GEN_MAX = SEG_HEAD_SLOT - 1;   // segments per chunk of the general path
+constexpr int SEG_GEN_MAX = SEG_HEAD_SLOT - 1;   // segments per chunk, at most
 constexpr uint32_t SEG_CHUNK_SPAN = SEG_TABLE_BLOCKS * SEG_BLOCK;  // values per chunk, at most
 
 struct RleChunkHead {
@@ -68,23 +68,13 @@ constexpr uint32_t DS_TILE_VALUES = 1024 * 20;
 static_assert(DS_TILE_VALUES <= SEG_TABLE_BLOCKS * SEG_BLOCK, "the block table covers a whole tile");
 constexpr uint32_t DS_MAX_PASSES = 32;
 
-// Everything the expansion kernel needs to know about a page (it does not read the descriptor).
-// The segment chunk of page p is pool[p * SEG_CHUNK ...].
+// Per-page record of the plan kernel.  `flags` belongs to the page with that index; `fallback_page`
+// is a dense list: entry i names the i-th page left to the generic kernel (their number is counter 1
+// of the call's counter block).
 struct RlePagePlan {
-  int32_t status;       // status of the header walk (PQD_OK, or the failure met at output index n_out)
-  uint32_t n_out;       // values covered by the segments
-  uint32_t consumed;    // stream bytes consumed (bytes_consumed of the result)
-  uint32_t nseg;
-  uint32_t w;           // bit width of the ids
-  uint32_t flags;       // PLAN_F_*
-  uint32_t stream_end;  // offset from `data` where the hybrid stream ends
-  uint32_t data_len;
-  uint64_t data;        // copies of the descriptor's pointers
-  uint64_t out;
-  uint64_t dict;
-  uint32_t dict_len;
-  uint32_t reserved;
+  uint32_t flags;          // PLAN_F_*
+  uint32_t fallback_page;
 };
-static_assert(sizeof(RlePagePlan) == 64, "plan record is 64 bytes");
+static_assert(sizeof(RlePagePlan) == 8, "plan record is 8 bytes");
 
 }  // namespace pqd
