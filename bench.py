@@ -353,6 +353,19 @@ def main():
                          "launches_timed": ncalls.value,
                          "other_launches_ms": {"k_rle_plan": round(plan_ms, 4), "k_rle_pages (left-over pages)": round(rest_ms, 4)}},
         }
+        # the reference's own CPU decoders need a JVM (scalar BytePacker; the Vector API plugin needs
+        # avx512vbmi + avx512_vbmi2 as well): probed here, run only where they exist
+        import shutil
+        flags = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                flags = next((ln for ln in f if ln.startswith("flags")), "")
+        except OSError:
+            pass
+        line["host"] = {"cpus": os.cpu_count(), "java": shutil.which("java"), "javac": shutil.which("javac"),
+                        "avx512_vbmi": " avx512_vbmi " in flags + " ", "avx512_vbmi2": " avx512_vbmi2 " in flags + " ",
+                        "reference_cpu_decoders": "not run: no JVM on this host" if not shutil.which("java") else
+                        "JVM present; the Java harness is not part of this repository"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 99, 1)
             line["cpu_baseline_16_threads"] = cpu_baseline(min(args.cpu_seconds, 5.0), 99, 16)
