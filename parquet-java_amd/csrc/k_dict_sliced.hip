@@ -398,8 +398,11 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     PROF(1)
 
     // ---- 2. ids beyond the dictionary: note the first one, and look up entry 0 instead.
-    // A page whose id width cannot express such an id skips the check.
-    if (h.w >= 32 || (1u << h.w) > dict_len) {
+    // A page whose ids cannot express such an id skips the check.  What counts is the width in whole
+    // bytes: the value of an RLE run is ceil(w/8) bytes and is not masked to w bits
+    // (BytesUtils.readIntLittleEndianPaddedOnBitWidth), so a 3-bit page may well hold the id 200.
+    const uint32_t id_bits = (h.w + 7u) & ~7u;
+    if (id_bits >= 32 || (1u << id_bits) > dict_len) {
       uint32_t bad = ~0u;
 #pragma unroll
       for (int k = UNITS - 1; k >= 0; --k) {

@@ -1,0 +1,112 @@
+"""Garbage in: random and half-random byte strings through the hybrid, dictionary and delta decoders.
+The kernels must neither fault nor write outside their buffers, and status, values_written and the
+values delivered must be those of the oracle (the Java decoders throw at the same value)."""
+import numpy as np
+import pytest
+
+
+def junk_streams(rng, count, max_len):
+    """Byte strings that look like hybrid streams often enough to get deep into the decoders: small
+    header-like bytes mixed with arbitrary ones."""
+    out = []
+    for _ in range(count):
+        n = int(rng.integers(0, max_len))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            b = rng.integers(0, 32, n, dtype=np.uint8)
+        else:
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+            b[rng.random(n) < 0.5] = rng.integers(0, 12)
+            if kind == 3 and n:
+                b[rng.integers(0, n, max(n // 16, 1))] = rng.integers(128, 256)
+        out.append(b)
+    return out
+
+
+def test_oracle_survives_garbage(orc):
+    rng = np.random.default_rng(404)
+    for data in junk_streams(rng, 300, 300):
+        w = int(rng.integers(0, 33))
+        n = int(rng.integers(0, 3000))
+        st, vals, used = orc.rle_decode(w, data, n)
+        assert 0 <= st <= 5 and vals.size <= n
+        st, vals, total, used = orc.delta_decode(data, 4000)
+        assert 0 <= st <= 5
+
+
+@pytest.mark.gpu
+def test_gpu_hybrid_garbage(orc, rle_path):
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(405)
+    pages, expect = [], []
+    for data in junk_streams(rng, 600, 400):
+        w = int(rng.integers(0, 33))
+        n = int(rng.integers(0, 5000))
+        flags = int(rng.choice([0, 0, pq.F_LENGTH_PREFIX, pq.F_WIDTH_PREFIX]))
+        if flags == pq.F_WIDTH_PREFIX:
+            ost, ovals = orc.dict_decode_ids(data, n)
+            if data.size and data[0] > 32:
+                continue  # widths above 32: the readers reject them in different ways, covered elsewhere
+        else:
+            ost, ovals, _ = orc.rle_decode(w, data, n, prefixed=bool(flags))
+        pages.append(gh.Page(data, n, pq.ENC_RLE, 4, bit_width=w, flags=flags))
+        expect.append((ost, ovals))
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(gh.decode_pages(pages), expect)):
+        assert st == ost and written == ovals.size, (i, st, ost, written, ovals.size, pages[i].bit_width, pages[i].flags)
+        assert (out.view(np.int32)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elem", [4, 8])
+def test_gpu_dictionary_garbage(orc, elem, dict_path):
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(406 + elem)
+    dt = np.int32 if elem == 4 else np.int64
+    dicts = [rng.integers(-1000, 1000, k).astype(dt) for k in (1, 7, 300, 5000)]
+    pages, expect = [], []
+    for data in junk_streams(rng, 400, 400):
+        if data.size and data[0] > 32:
+            data = data.copy()
+            data[0] = rng.integers(0, 33)
+        dic = dicts[int(rng.integers(0, len(dicts)))]
+        n = int(rng.integers(0, 5000))
+        pages.append(gh.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        expect.append(orc.dict_decode(data, dic, n))
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(gh.decode_pages(pages), expect)):
+        assert st == ost and written == ovals.size, (i, st, ost, written, ovals.size)
+        assert (out.view(dt)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elem", [4, 8])
+def test_gpu_delta_garbage(orc, elem):
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(407 + elem)
+    dt = np.int32 if elem == 4 else np.int64
+    pages, expect = [], []
+    good = orc.delta_encode(rng.integers(-1000, 1000, 700).astype(dt))
+    for k, data in enumerate(junk_streams(rng, 300, 300)):
+        if k % 3 == 0:  # a valid page with a few bytes damaged, or cut short
+            data = good.copy()
+            hits = rng.integers(4, data.size, int(rng.integers(1, 4)))
+            data[hits] = rng.integers(0, 256, hits.size)
+            data = data[:int(rng.integers(1, data.size + 1))]
+        cap = int(rng.integers(0, 3000))
+        ost, ovals, total, used = orc.delta_decode(data, cap)
+        pages.append(gh.Page(data, cap, pq.ENC_DELTA_BINARY_PACKED, elem))
+        expect.append((ost, ovals.astype(dt) if ost == 0 else ovals, total))
+    for i, ((st, written, _, out, guard), (ost, ovals, total)) in enumerate(zip(gh.decode_pages(pages), expect)):
+        assert st == ost, (i, st, ost)
+        if ost == 0:
+            assert written == total and (out.view(dt)[:written] == ovals[:written]).all(), i
+        assert (guard == 0xA5).all()

@@ -600,3 +600,23 @@ def test_pages_that_find_the_chunk_pool_full(gpu, orc, monkeypatch, limit):
             expect.append(dic[ids])
         for (st, written, _, out, guard), exp in zip(gpu.decode_pages(pages), expect):
             assert st == 0 and written == exp.size and (out.view(dt) == exp).all() and (guard == 0xA5).all()
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+def test_dictionary_rle_value_wider_than_the_id_width(gpu, orc, elem, dict_path):
+    """The value of an RLE run is ceil(w/8) bytes and is NOT masked to w bits
+    (BytesUtils.readIntLittleEndianPaddedOnBitWidth, BytesUtils.java:124-142): a page of 3-bit ids
+    can refer to entry 200.  Valid with 300 entries, out of range with 100."""
+    import parquet_java_amd as pq
+    dt = np.int32 if elem == 4 else np.int64
+    packed = orc.pack(3, np.arange(8, dtype=np.int32) % 8)
+    page = np.concatenate([np.array([3, (1 << 1) | 1], np.uint8), packed, np.array([10 << 1, 200, 2 << 1, 5], np.uint8)])
+    res = []
+    for entries in (300, 100):
+        dic = (np.arange(entries) * 7 - 3).astype(dt)
+        p = gpu.Page(page, 20, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic)
+        (st, written, _, out, guard), = gpu.decode_pages([p])
+        ost, ovals = orc.dict_decode(page, dic, 20)
+        assert st == ost and written == ovals.size and (out.view(dt)[:written] == ovals).all() and (guard == 0xA5).all()
+        res.append((st, written))
+    assert res == [(0, 20), (pq.DICT_OOB, 8)]
