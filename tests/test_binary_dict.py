@@ -220,3 +220,27 @@ def test_gpu_reader_mirror_reads_java_written_binary_pages(orc):
     assert [r.readBytes() for _ in range(ids.size)] == [raw[i * 5:i * 5 + 5].tobytes() for i in ids]
     with pytest.raises(pq.IllegalArgumentException):
         pq.PlainBinaryDictionary(raw.tobytes(), 8, 0)
+
+
+@pytest.mark.gpu
+def test_gpu_materialize_garbage_views(orc):
+    """Views that point anywhere: outside the dictionary, overlapping, empty, long, invalid."""
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(13)
+    cases = []
+    for k in range(120):
+        dict_len = int(rng.choice([0, 1, 15, 16, 17, 100, 5000]))
+        dict_bytes = rng.integers(0, 256, dict_len, dtype=np.uint8)
+        n = int(rng.integers(0, 6000))
+        off = rng.integers(0, dict_len + (12 if k % 4 == 0 else 1), n).astype(np.uint64)
+        ln = rng.integers(0, int(rng.choice([1, 9, 17, 40, 3000])), n).astype(np.uint64)
+        if k % 4:
+            ln = np.minimum(ln, np.uint64(dict_len) - np.minimum(off, np.uint64(dict_len)))  # mostly valid views
+        views = (ln << np.uint64(32)) | off
+        if k % 7 == 0 and n:
+            views[rng.integers(0, n, 2)] = INVALID
+        total = int(ln.sum())
+        cases.append((views, dict_bytes, int(rng.choice([total, total // 2, total + 5, 0]))))
+    check_pages(gh, orc, cases)

@@ -110,3 +110,66 @@ def test_gpu_delta_garbage(orc, elem):
         if ost == 0:
             assert written == total and (out.view(dt)[:written] == ovals[:written]).all(), i
         assert (guard == 0xA5).all()
+
+
+def damaged_regular_pages(orc, rng, count, widths, sizes):
+    """Pages as parquet-java writes them for non-repeating values (equal bit-packed runs), with a few
+    bytes overwritten (run headers among them), cut short, or asked for more or fewer values."""
+    out = []
+    for k in range(count):
+        w = int(widths[k % len(widths)])
+        n = int(sizes[k % len(sizes)])
+        vals = rng.integers(0, 1 << w, n, dtype=np.uint64).astype(np.uint32).view(np.int32)
+        if k % 4 == 1:
+            vals[n // 3:n // 3 + 300] = vals[0]  # an RLE run inside
+        data = orc.rle_encode(w, vals).copy()
+        stride = 1 + 63 * w
+        for _ in range(int(rng.integers(0, 4))):
+            if rng.random() < 0.6:  # a run header
+                at = int(rng.integers(0, max(data.size // stride, 1))) * stride
+            else:
+                at = int(rng.integers(0, data.size))
+            data[min(at, data.size - 1)] = rng.integers(0, 256)
+        if k % 3 == 0:
+            data = data[:int(rng.integers(max(data.size // 2, 1), data.size + 1))]
+        want = n if k % 5 else int(n * rng.uniform(0.3, 1.4))
+        out.append((w, data, want))
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_damaged_regular_hybrid_pages(orc, rle_path):
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(511)
+    cases = damaged_regular_pages(orc, rng, 60, (1, 2, 3, 5, 8, 12, 16, 20, 32), (70_000, 33_000, 140_000, 9_000, 65_536))
+    pages = [gh.Page(d, n, pq.ENC_RLE, 4, bit_width=w) for w, d, n in cases]
+    for i, ((w, d, n), (st, written, consumed, out, guard)) in enumerate(zip(cases, gh.decode_pages(pages))):
+        ost, ovals, oused = orc.rle_decode(w, d, n)
+        assert st == ost and written == ovals.size, (i, w, n, st, ost, written, ovals.size)
+        assert (out.view(np.int32)[:written] == ovals).all(), (i, w)
+        if ost == 0 and n:
+            assert consumed == oused, (i, consumed, oused)
+        assert (guard == 0xA5).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elem", [4, 8])
+def test_gpu_damaged_regular_dictionary_pages(orc, elem, dict_path):
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(512 + elem)
+    dt = np.int32 if elem == 4 else np.int64
+    cases = damaged_regular_pages(orc, rng, 40, (2, 7, 10, 12, 16), (20_000, 45_000, 70_000, 3_000))
+    pages, expect = [], []
+    for w, d, n in cases:
+        dic = rng.integers(-(1 << 31), 1 << 31, max((1 << w) - int(rng.integers(0, 3)), 1)).astype(dt)
+        data = np.concatenate([np.array([w], np.uint8), d])
+        pages.append(gh.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        expect.append(orc.dict_decode(data, dic, n))
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(gh.decode_pages(pages), expect)):
+        assert st == ost and written == ovals.size, (i, cases[i][0], st, ost, written, ovals.size)
+        assert (out.view(dt)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all()
