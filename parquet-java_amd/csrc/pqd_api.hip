@@ -272,7 +272,22 @@ int pqd_stream_create(void** stream) {
   return PQD_OK;
 }
 int pqd_stream_destroy(void* stream) {
-  if (stream) PQD_HIP(hipStreamDestroy(as_stream(stream)));
+  if (!stream) return PQD_OK;
+  PQD_HIP(hipStreamSynchronize(as_stream(stream)));
+  {  // the scratch the planned paths kept for this stream (on any device) goes with it
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    for (auto it = g_plan_scratch.begin(); it != g_plan_scratch.end();) {
+      if (it->first.second == stream) {
+        if (it->second.plans) (void)hipFree(it->second.plans);
+        if (it->second.gen_pool) (void)hipFree(it->second.gen_pool);
+        if (it->second.counters) (void)hipFree(it->second.counters);
+        it = g_plan_scratch.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  PQD_HIP(hipStreamDestroy(as_stream(stream)));
   return PQD_OK;
 }
 int pqd_stream_sync(void* stream) {
