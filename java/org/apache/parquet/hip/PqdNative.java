@@ -52,6 +52,15 @@ public final class PqdNative {
       FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS), Linker.Option.critical(true));
   static final MethodHandle DECODE_PAGES = h("pqd_decode_pages",
       FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+  // dictionaries: pqd_dict_create(physical_type, type_length, page, page_len, n_entries, &dict) replaces
+  // Encoding.PLAIN.initDictionary; pqd_decode_binary_page replaces the readBytes() loop of a
+  // DictionaryValuesReader over a PlainBinaryDictionary (offsets[n+1] + bytes come back)
+  static final MethodHandle DICT_CREATE = h("pqd_dict_create",
+      FunctionDescriptor.of(JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS), Linker.Option.critical(true));
+  static final MethodHandle DICT_DESTROY = h("pqd_dict_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+  static final MethodHandle DECODE_BINARY_PAGE = h("pqd_decode_binary_page",
+      FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS),
+      Linker.Option.critical(true));
   static final MethodHandle DEVICE_COUNT = h("pqd_device_count", FunctionDescriptor.of(JAVA_INT));
   static final MethodHandle INIT = h("pqd_init", FunctionDescriptor.of(JAVA_INT, JAVA_INT));
   static final MethodHandle LAST_ERROR = h("pqd_last_error", FunctionDescriptor.of(ADDRESS));
