@@ -152,7 +152,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (PQD_BENCH_FORCE_DIST=1 takes the process-group path with a single rank too: a rehearsal on a one-GPU box)
+    distributed = world > 1 or bool(os.environ.get("PQD_BENCH_FORCE_DIST"))
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
