@@ -364,7 +364,7 @@ def main():
         except OSError:
             pass
         line["host"] = {"cpus": os.cpu_count(), "java": shutil.which("java"), "javac": shutil.which("javac"),
-                        "avx512_vbmi": " avx512_vbmi " in flags + " ", "avx512_vbmi2": " avx512_vbmi2 " in flags + " ",
+                        "avx512vbmi": " avx512vbmi " in flags + " ", "avx512_vbmi2": " avx512_vbmi2 " in flags + " ",
                         "reference_cpu_decoders": "not run: no JVM on this host" if not shutil.which("java") else
                         "JVM present; the Java harness is not part of this repository"}
         if world == 1 and args.cpu_seconds > 0:
