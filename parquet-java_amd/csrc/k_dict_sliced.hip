@@ -42,7 +42,11 @@ constexpr int DS_SEG_BYTES = SEG_CHUNK * 8;         // one chunk of the plan: se
 
 constexpr int DS_OFF_SEGS = 2 * DS_SLICE_BYTES;  // three chunk buffers
 constexpr int DS_OFF_STATE = DS_OFF_SEGS + 3 * DS_SEG_BYTES;
-constexpr int DS_LDS_BYTES = DS_OFF_STATE + 64;
+// per wave: a list of up to 64 units left to the value-by-value pass (4 bytes each) and their ids (16 bytes each)
+constexpr int DS_SLOW_UNITS = 64;
+constexpr int DS_SLOW_BYTES = DS_SLOW_UNITS * (4 + 16);
+constexpr int DS_OFF_SLOW = DS_OFF_STATE + 64;
+constexpr int DS_LDS_BYTES = DS_OFF_SLOW + DS_WAVES * DS_SLOW_BYTES;
 static_assert(DS_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(DS_OFF_STATE % 16 == 0, "state block alignment");
 static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag bit per value");
@@ -255,13 +259,17 @@ __device__ __forceinline__ uint32_t unit_value(uint32_t lo, uint32_t hi, uint32_
   return funnel_shr(lo, hi, off) & ((1u << w) - 1u);
 }
 
-// Turns the fetched dwords into ids (values at or beyond t1 become 0).
+// Turns the fetched dwords into ids (values at or beyond t1 become 0).  Units that straddle runs, lie
+// in a run cut short by the end of the stream, or hold ids wider than 16 bits are not decoded by
+// their lane: the wave collects them in its LDS list (`slow`: DS_SLOW_UNITS entries, then their
+// ids) and decodes them one VALUE per lane, 16 units per step, so that pages with many short runs
+// do not walk every lane through the value-by-value code for each of its units.
 template <int UNITS>
 __device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, const PageHead& h, uint32_t tid,
-                                        const UnitRaw (&raw)[UNITS], uint32_t (&id)[UNITS * 4]) {
+                                        const UnitRaw (&raw)[UNITS], uint32_t (&id)[UNITS * 4], PQD_LDS uint32_t* slow) {
   const uint32_t t1 = h.v1;
   const uint32_t w = h.w <= 16 ? h.w : 0u;  // wider ids never take the 12-byte path
-  bool any_slow = false;
+  uint32_t slow_bits = 0;  // bit k: unit k of this lane is left to the list
 #pragma unroll
   for (int k = 0; k < UNITS; ++k) {
     const uint32_t kind = (raw[k].meta >> 8) & 3u;
@@ -281,45 +289,59 @@ __device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, const PageHead
       id[4 * k + 1] = packed ? a1 : other;
       id[4 * k + 2] = packed ? a2 : other;
       id[4 * k + 3] = packed ? a3 : other;
-      any_slow |= kind == UK_SLOW;
+      slow_bits |= kind == UK_SLOW ? 1u << k : 0u;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(any_slow)) {  // rare: run boundaries off multiples of four, truncated runs, wide ids
-    const uint32_t mask = mask32(h.w);
-#pragma unroll 1
+  if (__builtin_amdgcn_ballot_w64(slow_bits != 0) == 0) return;
+  const uint32_t lane = tid & 63u, wave_tid0 = tid & ~63u;
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t mask = mask32(h.w);
+  PQD_LDS uint32_t* list = slow;
+  PQD_LDS uint32_t* res = slow + DS_SLOW_UNITS;
+  for (;;) {  // rounds of up to DS_SLOW_UNITS units (wave-uniform)
+    uint32_t base = 0, mypos[UNITS];
+#pragma unroll
     for (int k = 0; k < UNITS; ++k) {
-      uint32_t meta = 0;
-#pragma unroll
-      for (int kk = 0; kk < UNITS; ++kk) meta = kk == k ? raw[kk].meta : meta;  // k is not a compile-time constant
-      if (((meta >> 8) & 3u) != UK_SLOW) continue;
-      const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-      uint32_t t = meta >> 16;
-      uint32_t v[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t g = g0 + j;
-        if (g >= t1) continue;
-        while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
-        const uint32_t tk = cs[t].start4, src = cs[t].src;
-        if (tk & SEG_PACKED_BIT) {
-          const uint32_t byte0 = h.in_off + src;
-          const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
-          const uint32_t wi = (byte0 >> 2) + (bitrel >> 5);
-          v[j] = funnel_shr(guarded_word(h, wi), guarded_word(h, wi + 1), bitrel & 31u) & mask;
-        } else {
-          v[j] = src;
+      const bool pending = (slow_bits >> k) & 1u;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(pending);
+      const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & below);
+      mypos[k] = pending && pos < (uint32_t)DS_SLOW_UNITS ? pos : ~0u;
+      if (mypos[k] != ~0u) list[pos] = lane | ((uint32_t)k << 6) | ((raw[k].meta >> 16) << 16);
+      base += (uint32_t)__builtin_popcountll(m);
+    }
+    const uint32_t n = base < (uint32_t)DS_SLOW_UNITS ? base : (uint32_t)DS_SLOW_UNITS;
+    for (uint32_t b0 = 0; b0 < n; b0 += 16) {
+      const uint32_t idx = b0 + (lane >> 2), j = lane & 3u;
+      if (idx < n) {
+        const uint32_t e = list[idx];
+        const uint32_t g = h.v0 + 4 * (((e >> 6) & 7u) * DS_THREADS + wave_tid0 + (e & 63u)) + j;
+        uint32_t t = e >> 16, v = 0;
+        if (g < t1) {
+          while (cs[t + 1].start4 <= g * 4 + 3) ++t;  // stops at the sentinel (start == v1 > g)
+          const uint32_t tk = cs[t].start4, src = cs[t].src;
+          v = src;
+          if (tk & SEG_PACKED_BIT) {
+            const uint32_t byte0 = h.in_off + src;
+            const uint32_t bitrel = (byte0 & 3u) * 8 + (g - (tk >> 2)) * h.w;
+            const uint32_t wi = (byte0 >> 2) + (bitrel >> 5);
+            v = funnel_shr(guarded_word(h, wi), guarded_word(h, wi + 1), bitrel & 31u) & mask;
+          }
         }
-      }
-#pragma unroll
-      for (int kk = 0; kk < UNITS; ++kk) {
-        if (kk == k) {
-          id[4 * kk] = v[0];
-          id[4 * kk + 1] = v[1];
-          id[4 * kk + 2] = v[2];
-          id[4 * kk + 3] = v[3];
-        }
+        res[idx * 4 + j] = v;
       }
     }
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      if (mypos[k] != ~0u) {
+        const u32x4 r = *(const PQD_LDS u32x4*)(res + mypos[k] * 4);
+        id[4 * k] = r.x;
+        id[4 * k + 1] = r.y;
+        id[4 * k + 2] = r.z;
+        id[4 * k + 3] = r.w;
+        slow_bits &= ~(1u << k);
+      }
+    }
+    if (base <= (uint32_t)DS_SLOW_UNITS) break;
   }
 }
 
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
     // ---- 1. ids into registers (their packed dwords were requested one page ago)
     uint32_t id[R];
-    extract<UNITS>(cs, h, tid, raw, id);
+    extract<UNITS>(cs, h, tid, raw, id, (PQD_LDS uint32_t*)(lds + DS_OFF_SLOW + wave * DS_SLOW_BYTES));
     PROF(1)
 
     // ---- 2. ids beyond the dictionary: note the first one, and look up entry 0 instead.
