@@ -3,14 +3,17 @@
 bytes (encoded bytes read + decoded bytes written) per second against the 8 TB/s HBM peak.
 Pages come from the CPU encoders of the oracle (a few distinct pages, replicated on the device).
 
-    python tools/kernel_rates.py
+    python tests/perf/kernel_rates.py
+
+It lives under tests/ because it uses the oracle's ENCODERS to synthesise pages (the oracle is test
+infrastructure; nothing outside tests/, the smoke check and the benchmark's CPU baseline touches it).
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
