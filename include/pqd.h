@@ -102,6 +102,9 @@ int pqd_dev_alloc(void** p, size_t bytes);
 int pqd_dev_free(void* p);
 int pqd_host_alloc_pinned(void** p, size_t bytes);
 int pqd_host_free_pinned(void* p);
+/* the same two under their shorter names */
+int pqd_alloc_pinned(void** p, size_t bytes);
+int pqd_free_pinned(void* p);
 int pqd_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int pqd_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int pqd_memset_dev(void* dst_dev, int value, size_t bytes, void* stream);

@@ -96,4 +96,26 @@ public final class PqdNative {
       default: throw new IllegalStateException(what + ": " + lastError());
     }
   }
+  /** One step of the per-step packer interface: `count` values of `bitWidth` bits from in[inPos...] to out[outPos...]. */
+  public static void unpackI32(int bitWidth, byte[] in, int inPos, int[] out, int outPos, int count) {
+    unpackI32(bitWidth, MemorySegment.ofArray(in), inPos, out, outPos, count);
+  }
+
+  public static void unpackI32(int bitWidth, java.nio.ByteBuffer in, int inPos, int[] out, int outPos, int count) {
+    unpackI32(bitWidth, MemorySegment.ofBuffer(in), inPos, out, outPos, count);
+  }
+
+  private static void unpackI32(int bitWidth, MemorySegment in, int inPos, int[] out, int outPos, int count) {
+    if (count == 0) return;
+    long bytes = (long) count * bitWidth / 8;
+    try {
+      int st = (int) UNPACK_I32.invokeExact(bitWidth, in.asSlice(inPos, bytes), bytes,
+          MemorySegment.ofArray(out).asSlice(4L * outPos, 4L * count), (long) count);
+      if (st != OK) throw new RuntimeException("pqd_unpack_i32: " + lastError());
+    } catch (RuntimeException e) {
+      throw e;
+    } catch (Throwable t) {
+      throw new RuntimeException(t);
+    }
+  }
 }

@@ -56,6 +56,8 @@ EXPORTS = {
     "pqd_dev_free": ([C.c_void_p], C.c_int),
     "pqd_host_alloc_pinned": ([C.POINTER(C.c_void_p), C.c_size_t], C.c_int),
     "pqd_host_free_pinned": ([C.c_void_p], C.c_int),
+    "pqd_alloc_pinned": ([C.POINTER(C.c_void_p), C.c_size_t], C.c_int),
+    "pqd_free_pinned": ([C.c_void_p], C.c_int),
     "pqd_memcpy_h2d": ([C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
     "pqd_memcpy_d2h": ([C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
     "pqd_memset_dev": ([C.c_void_p, C.c_int, C.c_size_t, C.c_void_p], C.c_int),

@@ -252,6 +252,8 @@ int pqd_host_free_pinned(void* p) {
   if (p) PQD_HIP(hipHostFree(p));
   return PQD_OK;
 }
+int pqd_alloc_pinned(void** p, size_t bytes) { return pqd_host_alloc_pinned(p, bytes); }
+int pqd_free_pinned(void* p) { return pqd_host_free_pinned(p); }
 int pqd_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes) PQD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
   return PQD_OK;
