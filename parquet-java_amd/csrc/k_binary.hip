@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
       for (int j = 0; j < BN_VPL; j += 4) {
         const u32x4_a4 o4 = {running + pre[j], running + pre[j + 1], running + pre[j + 2], running + pre[j + 3]};
-        *(PQD_GLOBAL u32x4_a4*)(offsets + g0 + j) = o4;
+        PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(offsets + g0 + j), o4);
       }
     } else {
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         ((u32x4*)win)[i] = u32x4{0u, 0u, 0u, 0u};
         const uint32_t p0 = i * 16u;
         if (p0 >= s && p0 + 16u <= end) {
-          *(PQD_GLOBAL u32x4*)(gdst - s + p0) = v;
+          PQD_STREAM_STORE((PQD_GLOBAL u32x4*)(gdst - s + p0), v);
         } else {  // the first and the last piece of a window: only the bytes that belong to it
 #pragma unroll 1
           for (uint32_t k = 0; k < 16u; ++k) {

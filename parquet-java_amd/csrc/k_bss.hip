@@ -70,7 +70,7 @@ __global__ __launch_bounds__(BSS_THREADS) void k_bss_pages(const pqd_page_desc* 
       for (int s = 0; s < 4; ++s) x[s] = load_u32_unaligned(in + (size_t)s * n + (size_t)u * 4);
       transpose4x4(x, y);
       u32x4_a4 r = {y[0], y[1], y[2], y[3]};
-      *reinterpret_cast<u32x4_a4*>(out + (size_t)u * 16) = r;
+      PQD_STREAM_STORE(reinterpret_cast<u32x4_a4*>(out + (size_t)u * 16), r);
     }
   } else if (K == 8) {
     for (uint32_t u = blockIdx.x * BSS_THREADS + threadIdx.x; u < n_units; u += stride) {

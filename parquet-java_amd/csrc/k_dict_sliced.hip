@@ -581,7 +581,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
         PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
         if (g0 + 4 <= n_out) {
           u32x4_a4 r4 = {vlo[4 * k], vlo[4 * k + 1], vlo[4 * k + 2], vlo[4 * k + 3]};
-          *(PQD_GLOBAL u32x4_a4*)(o) = r4;
+          PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o), r4);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -592,8 +592,8 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
         if (g0 + 4 <= n_out) {
           u32x4_a4 r0 = {vlo[4 * k], vhi[ELEM == 8 ? 4 * k : 0], vlo[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
           u32x4_a4 r1 = {vlo[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], vlo[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
-          *(PQD_GLOBAL u32x4_a4*)(o) = r0;
-          *(PQD_GLOBAL u32x4_a4*)(o + 2) = r1;
+          PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o), r0);
+          PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o + 2), r1);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)

@@ -281,7 +281,7 @@ __device__ __forceinline__ void expand_regular_tile(const ExHead& h, uint32_t st
 #pragma unroll
       for (int j = 0; j < VPU; j += 4) {
         const u32x4_a4 r4 = {a[j], a[j + 1], a[j + 2], a[j + 3]};
-        *(PQD_GLOBAL u32x4_a4*)(out + g0 + j) = r4;
+        PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(out + g0 + j), r4);
       }
     }
   }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_unpack_run_i32(const uint8_t* __restric
     r.z = wnd.d0 & mask;
     wnd.drop(w);
     r.w = wnd.d0 & mask;
-    *reinterpret_cast<u32x4_a4*>(out + u * 4) = r;
+    PQD_STREAM_STORE(reinterpret_cast<u32x4_a4*>(out + u * 4), r);
   }
 }
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_unpack_run_i64(const uint8_t* __restric
     r.y = (uint32_t)(a >> 32);
     r.z = (uint32_t)b;
     r.w = (uint32_t)(b >> 32);
-    *reinterpret_cast<u32x4_a4*>(out + u * 2) = r;
+    PQD_STREAM_STORE(reinterpret_cast<u32x4_a4*>(out + u * 2), r);
   }
 }
 

@@ -6,6 +6,11 @@
 
 #include "../../include/pqd.h"
 
+// Store of decoded output: written once, never read again by the kernels.  The nontemporal hint
+// keeps those lines from settling in L2, where they would push out what the kernels do read again
+// (dictionary slices, plan chunks) and fill the write-back capacity in bursts.
+#define PQD_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+
 namespace pqd {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));

@@ -197,6 +197,11 @@ def shard_of_mixed_row_groups():
         for d_descs, d_res, n_pages, enc, elem in calls:
             pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n_pages, enc, elem, stream)
     t = timeit(run, iters=5, warm=2)
+    parts = []
+    for name, (d_descs, d_res, n_pages, enc, elem) in zip(kinds, calls):
+        one = lambda: pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n_pages, enc, elem, stream)
+        parts.append(f"{name} {timeit(one, iters=5, warm=2) * 1e6:.0f}")
+    print("    per class, alone (us): " + ", ".join(parts), flush=True)
     for d_descs, d_res, n_pages, enc, elem in calls:
         status, written, _ = pq.results_from_numpy(d_res.cpu().numpy())
         assert (status == 0).all() and (written == n).all(), (enc, status[:4])
