@@ -51,6 +51,7 @@ struct DeltaState {
   uint32_t fast_base;     // table index of their first miniblock
   uint32_t spec_blocks;   // whole blocks found by wave 0 at the start of the current window ...
   uint32_t spec_bytes;    // ... and the stream bytes they take
+  uint32_t spec_len;      // length of the latest block wave 0 found: the first guess in the next window
 };
 
 __device__ __forceinline__ bool lds_varint(lds_words_t win, int32_t base, uint32_t& p, uint32_t end,
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       st.total = (uint32_t)total;
       st.first = (uint64_t)zigzag64(first_raw);
       st.min_delta = 0;
+      st.spec_len = 0;
     }
     __syncthreads();
   }
@@ -209,39 +211,50 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
     }
     // ---- 2. block-header walk (loadNewBlockToBuffer, :121-143; readBitWidthsForMiniBlocks, :164-172)
     // 2a. Wave 0, all lanes at once, for stretches of blocks of one length L (steady delta widths):
-    // lane t looks at offset t * L behind the stretch's first block and checks that a full block of
-    // that same length starts there.  The blocks up to the first lane that says no are taken as
-    // found; the next stretch starts at that block, with its length.  The walk ends where a block
-    // is not wholly wanted, does not fit the window or does not pass the quick checks: lane 0
-    // carries on from there below.
+    // lane t looks at offset t * L behind the stretch's first block, checks that a whole block
+    // starts there and works out its length.  The blocks up to the first lane whose length is not L
+    // are found, and so is that lane's block (it does start where the lane looked); its length is
+    // the guess for the next stretch, so a step costs one look at the window and always advances
+    // by a block at least.  The walk ends where a block is not wholly wanted, does not fit the
+    // window or does not pass the quick checks: lane 0 carries on from there below.
     uint32_t spec_m = 0, spec_bytes = 0;
     if (tid < 64) {
       const int32_t base = first_window ? st.window_base : wbase;
       const uint32_t wend = (uint32_t)(base + DWINDOW_BYTES);
       const uint32_t mn = st.mini_n, bs = st.block_size;
       uint32_t p = st.pos, scanned = st.deltas_done, found = 0;
+      uint32_t L = st.spec_len;  // the latest block length seen in this page (0: none yet)
       const bool can = st.minis_left == 0 && mn <= 8 && mn > 0;
-      while (can && found < (uint32_t)MAX_FAST_BLOCKS && p + 16 <= end && p + 16 <= wend) {
-        uint32_t nbv0, wsum0;
-        const bool ok0 = quick_block<true>(win, (uint32_t)(p - base), mn, mn, nbv0, wsum0);
-        const uint32_t L = nbv0 + mn + (mini_size >> 3) * wsum0;
+      while (can && found < (uint32_t)MAX_FAST_BLOCKS) {
         const uint64_t pt = (uint64_t)p + (uint64_t)tid * L;
-        bool ok = false;
-        if (ok0 && pt + 16 <= end && pt + 16 <= wend && pt + L <= end && pt + L <= wend &&
-            (uint64_t)scanned + (uint64_t)(tid + 1) * bs <= n_deltas && (found + tid + 1) * mn <= (uint32_t)MAX_MINIS &&
-            found + tid < (uint32_t)MAX_FAST_BLOCKS) {
+        const uint32_t off = (uint32_t)(pt - base);
+        bool valid = false;
+        uint32_t len = 0;
+        if (pt + 16 <= end && pt + 16 <= wend && (uint64_t)scanned + (uint64_t)(tid + 1) * bs <= n_deltas &&
+            (found + tid + 1) * mn <= (uint32_t)MAX_MINIS && found + tid < (uint32_t)MAX_FAST_BLOCKS) {
           uint32_t nbv, wsum;
-          const uint32_t off = (uint32_t)(pt - base);
-          ok = quick_block(win, off, mn, mn, nbv, wsum) && nbv + mn + (mini_size >> 3) * wsum == L;
-          if (ok) blk_off[found + tid] = off;  // entries past the first refusal are overwritten or ignored
+          valid = quick_block(win, off, mn, mn, nbv, wsum);
+          len = nbv + mn + (mini_size >> 3) * wsum;
+          valid = valid && pt + len <= end && pt + len <= wend;
         }
-        const uint64_t no = ~__builtin_amdgcn_ballot_w64(ok);
-        const uint32_t m = no ? (uint32_t)__builtin_ctzll(no) : 64u;
-        if (m == 0) break;
-        found += m;
-        p += m * L;
-        scanned += m * bs;
+        const uint64_t no = ~__builtin_amdgcn_ballot_w64(valid && len == L);
+        const uint32_t m = no ? (uint32_t)__builtin_ctzll(no) : 64u;  // lanes 0..m-1: blocks of length L
+        // lane m looked at the right place too (every block before it has length L)
+        const uint32_t lm = m < 64u ? m : 0u;
+        const bool valid_m = m < 64u && __builtin_amdgcn_readlane((uint32_t)valid, lm) != 0u;
+        const uint32_t len_m = __builtin_amdgcn_readlane(len, lm);
+        const uint32_t take = m + (valid_m ? 1u : 0u);
+        if (take == 0) break;
+        if (tid < take) blk_off[found + tid] = off;
+        found += take;
+        p += m * L + (valid_m ? len_m : 0u);
+        scanned += take * bs;
+        if (m < 64u) {
+          if (!valid_m) break;
+          L = len_m;
+        }
       }
+      if (tid == 0) st.spec_len = L;
       if (tid == 0) {
         st.spec_blocks = found;
         st.spec_bytes = p - st.pos;

@@ -139,6 +139,10 @@ def main():
         ps = [orc.delta_encode(ts), orc.delta_encode(ts[::-1].copy())][:1]
         run_pages(f"DELTA_BINARY_PACKED INT64, deltas ~{k} bits, 5000 pages x 20000", ps, 5000, 20000,
                   pq.ENC_DELTA_BINARY_PACKED, 8)
+    # the same 20-bit deltas, but every block's min delta takes the same number of varint bytes: all blocks of one length
+    ts = 1_600_000_000_000_000_000 + np.cumsum((1 << 20) + 1000 + rng.integers(0, 1 << 20, 20000)).astype(np.int64)
+    run_pages("DELTA_BINARY_PACKED INT64, deltas ~20 bits, blocks of one length, 5000 x 20000", [orc.delta_encode(ts)], 5000, 20000,
+              pq.ENC_DELTA_BINARY_PACKED, 8)
     # byte stream split
     for dt, k in ((np.float32, 4), (np.float64, 8)):
         raw = rng.standard_normal(20000).astype(dt)
