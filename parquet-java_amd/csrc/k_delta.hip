@@ -22,7 +22,7 @@
 namespace pqd {
 
 constexpr int DELTA_THREADS = 256;
-constexpr int DWINDOW_BYTES = 24 * 1024;
+constexpr int DWINDOW_BYTES = 16 * 1024;
 constexpr int DWINDOW_SLACK = 48;
 constexpr int DWINDOW_PIECES = (DWINDOW_BYTES + DWINDOW_SLACK) / 16;
 constexpr int MAX_MINIS = 1024;      // miniblock table entries per window
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   typedef typename std::conditional<ELEM == 8, uint64_t, uint32_t>::type acc_t;
   __shared__ u32x4 win4[DWINDOW_PIECES];
   __shared__ uint32_t mini_src[MAX_MINIS];
-  __shared__ uint32_t mini_w[MAX_MINIS];
+  __shared__ uint8_t mini_w[MAX_MINIS];  // widths are at most 64; as bytes the kernel fits four workgroups per CU
   __shared__ uint64_t mini_min[MAX_MINIS];
   __shared__ uint8_t cur_widths[MAX_MINI_PER_BLOCK];
   __shared__ acc_t wave_sum[DELTA_THREADS / 64];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
           break;
         }
         mini_src[nm] = (uint32_t)(p - base);
-        mini_w[nm] = w;
+        mini_w[nm] = (uint8_t)w;
         mini_min[nm] = min_delta;
         ++nm;
         p += bytes;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
           const uint32_t w = ldsb(win, q + i);
           const uint32_t e = st.fast_base + tid * mn + i;
           mini_src[e] = src;
-          mini_w[e] = w;
+          mini_w[e] = (uint8_t)w;
           mini_min[e] = md;
           src += (mini_size >> 3) * w;
         }

@@ -492,7 +492,7 @@ __device__ __forceinline__ void varint_of_dword(uint32_t x, uint32_t& header, ui
 // ints) are consumed by k_rle_expand, dictionary pages (want_dict == 1) by k_dict_pages_sliced,
 // whose workgroup holds a whole chunk in registers (hence the smaller span).  The page's result
 // is written here; the dictionary kernel amends it if it meets an id beyond the dictionary.
-__global__ __launch_bounds__(PLAN_THREADS) void k_rle_plan_chunks(const pqd_page_desc* __restrict__ descs,
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_rle_plan_chunks(const pqd_page_desc* __restrict__ descs,
                                                                   pqd_page_result* __restrict__ results,
                                                                   RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
