@@ -327,6 +327,12 @@ def test_delta_pages(gpu, orc, elem):
         step = rng.integers(0, 1 << k, n, dtype=np.uint64).astype(np.int64) + 1000 if k else np.full(n, 1000, np.int64)
         ts = (np.int64(1_600_000_000_000_000_000 if elem == 8 else 1000) + np.cumsum(step)).astype(dt)
         add(orc.delta_encode(ts), n)
+    for seed in (1, 2, 3):  # block lengths that change every few blocks: widths by regime, min-delta varints by a byte
+        r2 = np.random.default_rng(100 + seed)
+        parts = [r2.integers(0, 1 << int(k), int(m), dtype=np.uint64).astype(np.int64) + int(off)
+                 for k, m, off in zip(r2.integers(1, 30 if elem == 8 else 20, 40), r2.integers(100, 900, 40), r2.integers(0, 20000, 40))]
+        ts = (np.int64(1 << 40 if elem == 8 else 1000) + np.cumsum(np.concatenate(parts))).astype(dt)
+        add(orc.delta_encode(ts), ts.size)
     for block, mini in ((256, 8), (64, 1), (1024, 4), (2048, 16)):  # other configurations
         v = rng.integers(-(1 << 40), 1 << 40, 5000).astype(dt)
         add(orc.delta_encode(v, block, mini), 5000)
