@@ -14,12 +14,13 @@
 //     global memory (coalesced; each lane owns units of four consecutive values);
 //   - the dictionary streams through LDS in 64 KiB slices, double-buffered, by LDS-DMA
 //     (global_load_lds_dwordx4) issued by all 16 waves;
-//   - each pass resolves the ids that fall into the resident slice; a resolved id is replaced in
-//     place by its value;
+//   - each pass looks up the ids that fall into the resident slice (their values go to registers
+//     of their own; an id is found by exactly one pass);
 //   - while one page is being gathered, the next page's plan, segments and packed dwords are
 //     already being fetched (behind passes 0 and 1), so no memory round trip is exposed between
 //     pages;
-//   - the values are stored once, 16 bytes per lane, fully coalesced.
+//   - the values are stored once, 16 bytes per lane, with the nontemporal hint (they are not read
+//     again, and left in L2 they push out the dictionary slices).
 // HBM traffic per value: w/8 bytes of ids + ELEM bytes out; the slices are L2 traffic
 // (dictionary bytes per tile, i.e. a few bytes per value).  Small dictionaries (one slice) stay
 // resident across chunks.  Pages this kernel is not made for (ids wider than 16 bits, a dictionary
