@@ -388,15 +388,15 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   wg_barrier();
 
   // Long batches of 8-byte dictionaries that are swept through LDS: the workgroups start a few
-  // microseconds apart (eight phases).  Left alone they run in step, chunk after chunk, so the whole
+  // microseconds apart (32 phases of 0.4 us).  Left alone they run in step, chunk after chunk, so the whole
   // chip asks L2 for slices at one moment and writes its output at the next; out of step the two
-  // overlap.  Measured on 100 M values, 64 Ki entries: 359 -> 340 us including the delay; 4-byte
+  // overlap.  Measured on 100 M values, 64 Ki entries: 359 -> 334 us including the delay (eight phases of 1.7 us: 340); 4-byte
   // dictionaries gain nothing and short batches would only pay the delay, so they start at once.
   if (ELEM == 8 && share >= 16u) {
     const PQD_LDS RleChunkHead* hd0 = (const PQD_LDS RleChunkHead*)((const PQD_LDS RleSeg*)(lds + DS_OFF_SEGS) + SEG_HEAD_SLOT);
     if (uni(hd0->dict_len) > S) {
-      const uint32_t phase = (blockIdx.x >> 3) & 7u;  // blockIdx & 7 is the XCD: every XCD gets every phase
-      for (uint32_t i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(64);
+      const uint32_t phase = (blockIdx.x >> 3) & 31u;  // blockIdx & 7 is the XCD: its 32 workgroups get a phase each
+      for (uint32_t i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(16);
     }
   }
   UnitRaw raw[UNITS];  // packed dwords of the chunk about to be decoded
