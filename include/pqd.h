@@ -45,7 +45,7 @@ enum pqd_encoding {
   PQD_ENC_RLE = 1,                 /* RLE / bit-packing hybrid -> int32 (levels, booleans, dictionary ids) */
   PQD_ENC_RLE_DICTIONARY = 2,      /* 1-byte width + hybrid ids, gathered through a dictionary (also PLAIN_DICTIONARY data pages) */
   PQD_ENC_DELTA_BINARY_PACKED = 3, /* -> int32 / int64.  Limit of this library: one miniblock's packed bytes
-                                      (miniblock size x width / 8) must fit 16 KiB, else PQD_DECODE;
+                                      (miniblock size x width / 8) must fit 18 KiB, else PQD_DECODE;
                                       parquet-java's writers use 32-value miniblocks: 256 bytes at most */
   PQD_ENC_BYTE_STREAM_SPLIT = 4,   /* -> elem_size-byte elements */
   PQD_ENC_BIT_PACKED = 5           /* legacy MSB-first levels -> int32 */

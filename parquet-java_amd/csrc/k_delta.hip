@@ -22,10 +22,10 @@
 namespace pqd {
 
 constexpr int DELTA_THREADS = 256;
-constexpr int DWINDOW_BYTES = 16 * 1024;
+constexpr int DWINDOW_BYTES = 18 * 1024;
 constexpr int DWINDOW_SLACK = 48;
 constexpr int DWINDOW_PIECES = (DWINDOW_BYTES + DWINDOW_SLACK) / 16;
-constexpr int MAX_MINIS = 1024;      // miniblock table entries per window
+constexpr int MAX_MINIS = 896;      // miniblock table entries per window
 constexpr int MAX_MINI_PER_BLOCK = 256;
 constexpr int MAX_FAST_BLOCKS = DELTA_THREADS;  // blocks per window whose headers are expanded one per lane
 
