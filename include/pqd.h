@@ -14,6 +14,16 @@
  *     caller's buffer.
  *   - The library keeps no reference to caller memory after a host entry point returns, or after
  *     the stream work of a "_dev" entry point has completed.
+ *   - Threads.  Every entry point may be called from any number of host threads at once
+ *     (the reference's packers are shared singletons, parquet-encoding/.../Packer.java:113-121, and
+ *     ParquetReadRouter's static methods are re-entrant, ParquetReadRouter.java:71-103; a
+ *     ValuesReader instance itself stays single-threaded as in the reference).  The host-memory
+ *     entry points (pqd_unpack_i32/_i64, pqd_decode_page, pqd_decode_page_flat,
+ *     pqd_decode_binary_page) run on a stream and staging buffers owned by the calling thread;
+ *     pqd_thread_release() gives them back before a thread ends.  "_dev" calls and
+ *     pqd_decode_pages issued on the SAME stream from several threads are serialised inside the
+ *     library for as long as their launches are being enqueued; calls on different streams run
+ *     concurrently.
  *   - All bit-packed data is parquet's little-endian (LSB-first) packing unless stated otherwise.
  */
 #ifndef PQD_H
@@ -44,9 +54,10 @@ enum pqd_status {
 enum pqd_encoding {
   PQD_ENC_RLE = 1,                 /* RLE / bit-packing hybrid -> int32 (levels, booleans, dictionary ids) */
   PQD_ENC_RLE_DICTIONARY = 2,      /* 1-byte width + hybrid ids, gathered through a dictionary (also PLAIN_DICTIONARY data pages) */
-  PQD_ENC_DELTA_BINARY_PACKED = 3, /* -> int32 / int64.  Limit of this library: one miniblock's packed bytes
-                                      (miniblock size x width / 8) must fit 18 KiB, else PQD_DECODE;
-                                      parquet-java's writers use 32-value miniblocks: 256 bytes at most */
+  PQD_ENC_DELTA_BINARY_PACKED = 3, /* -> int32 / int64.  Limits of this library: one miniblock's packed bytes
+                                      (miniblock size x width / 8) must fit 18 KiB and a block may hold at
+                                      most 256 miniblocks, else PQD_DECODE; parquet-java's writers use 4
+                                      miniblocks of 32 values: 256 bytes at most */
   PQD_ENC_BYTE_STREAM_SPLIT = 4,   /* -> elem_size-byte elements */
   PQD_ENC_BIT_PACKED = 5           /* legacy MSB-first levels -> int32 */
 };
@@ -172,6 +183,24 @@ int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint3
  * initFromPage): stages data (+ dictionary) to the device, decodes, copies `out` back.
  */
 int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result);
+/*
+ * The same call with every pointer as a direct argument instead of a struct member, for bindings
+ * that can only pass heap arrays as arguments (java.lang.foreign Linker.Option.critical(true) with
+ * MemorySegment.ofArray, JNI GetPrimitiveArrayCritical): `data`, `dict` and `out` may then be the
+ * Java byte[] / int[] / long[] themselves (ParquetReadRouter.java:80-103 takes heap and direct
+ * buffers alike).  Arguments have the meaning of the pqd_page_desc members of the same name.
+ */
+int pqd_decode_page_flat(int encoding, int elem_size, int bit_width, uint32_t flags, const uint8_t* data,
+                         uint32_t data_len, uint32_t num_values, const void* dict, uint32_t dict_len, void* out,
+                         pqd_page_result* result);
+/*
+ * Frees what the host-memory entry points keep for the calling thread (its stream, device staging
+ * buffers, plan scratch, timing events).  Optional: a thread that ends without it releases the same
+ * things when the C++ runtime runs its thread-local destructors; call it from runtimes that end
+ * threads without running those (or before unloading the library).  The thread may go on calling
+ * the library afterwards.  No counterpart in the reference (the JVM collects its buffers).
+ */
+int pqd_thread_release(void);
 
 /* ---- dictionaries ----------------------------------------------------------------------------- */
 /* org.apache.parquet.format.Type numbering (PrimitiveTypeName of the column). */

@@ -18,7 +18,8 @@ import numpy as _np
 from . import _native
 from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
                       ENC_DELTA_BINARY_PACKED, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
-                      HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY, VIEW_INVALID,
+                      HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
+                      TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
                       BinaryPageDesc, DictInfo, PageDesc, PageResult, PqdError, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",

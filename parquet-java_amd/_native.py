@@ -78,6 +78,9 @@ EXPORTS = {
     "pqd_decode_pages_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "pqd_decode_pages": ([C.POINTER(PageDesc), C.POINTER(PageResult), C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_page": ([C.POINTER(PageDesc), C.POINTER(PageResult)], C.c_int),
+    "pqd_decode_page_flat": ([C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                              C.c_uint32, C.c_void_p, C.POINTER(PageResult)], C.c_int),
+    "pqd_thread_release": ([], C.c_int),
     "pqd_binary_dict_views": ([C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "pqd_dict_create": ([C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)], C.c_int),
     "pqd_dict_get": ([C.c_void_p, C.POINTER(DictInfo)], C.c_int),

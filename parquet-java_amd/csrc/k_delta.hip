@@ -224,7 +224,8 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       const uint32_t mn = st.mini_n, bs = st.block_size;
       uint32_t p = st.pos, scanned = st.deltas_done, found = 0;
       uint32_t L = st.spec_len;  // the latest block length seen in this page (0: none yet)
-      const bool can = st.minis_left == 0 && mn <= 8 && mn > 0;
+      // (miniblocks of at most 8192 values: the lengths below stay far inside 32 bits)
+      const bool can = st.minis_left == 0 && mn <= 8 && mn > 0 && mini_size <= 8192u;
       while (can && found < (uint32_t)MAX_FAST_BLOCKS) {
         const uint64_t pt = (uint64_t)p + (uint64_t)tid * L;
         const uint32_t off = (uint32_t)(pt - base);
@@ -298,12 +299,12 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
           status = PQD_DECODE;
           break;
         }
-        const uint32_t bytes = mini_bytes_unit * w;
+        const uint64_t bytes = (uint64_t)mini_bytes_unit * w;  // up to 2^28 * 64: not a 32-bit product
         if (end - p < bytes) {
           status = PQD_EOF;  // in.slice(w) past the end
           break;
         }
-        if (p + bytes > wend) {
+        if ((uint64_t)p + bytes > wend) {
           if (nm == 0) status = PQD_DECODE;  // a single miniblock larger than the staging window
           break;
         }
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
         mini_w[nm] = (uint8_t)w;
         mini_min[nm] = min_delta;
         ++nm;
-        p += bytes;
+        p += (uint32_t)bytes;
         scanned += mini_size;
         ++cm;
         --left;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       // below carries on from that block and reports what is wrong with it.
       uint32_t nblk = 0, last_take = st.mini_n;
       bool window_full = false;  // the walk stopped in front of a whole block that does not fit the window
-      if (left == 0 && st.mini_n <= 8 && status == PQD_OK) {
+      if (left == 0 && st.mini_n <= 8 && mini_size <= 8192u && status == PQD_OK) {
         const uint32_t mn = st.mini_n;
         // the blocks found by all lanes above
         nblk = spec_m;

@@ -650,7 +650,10 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 #endif
 }
 
-static int g_cu_count = 0;
+// Per device, set on the first launch there: the number of CUs and the dynamic-LDS attribute of the
+// two kernels (racing first launches write the same values).
+constexpr int DS_MAX_DEVICES = 64;
+static int g_cu_count[DS_MAX_DEVICES];
 #ifdef PQD_PROF
 static uint64_t* g_prof = nullptr;
 static void prof_report(uint32_t grid, hipStream_t stream) {
@@ -675,34 +678,32 @@ static void prof_report(uint32_t grid, hipStream_t stream) {
 hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
                                     uint32_t n_pages, int elem, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  if (g_cu_count == 0) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= DS_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (g_cu_count[dev] == 0) {
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, dev);
     if (e != hipSuccess) return e;
-    g_cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dict_pages_sliced<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dict_pages_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    __atomic_store_n(&g_cu_count[dev], prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, __ATOMIC_RELEASE);
   }
-  // one persistent workgroup per CU; each takes chunks blockIdx.x, blockIdx.x + gridDim.x, ... of
-  // however many the plan kernel made (a count only the device knows)
-  const uint32_t grid = n_pages < (uint32_t)g_cu_count ? n_pages : (uint32_t)g_cu_count;
+  const int cus = __atomic_load_n(&g_cu_count[dev], __ATOMIC_ACQUIRE);
+  // one persistent workgroup per CU; each takes a contiguous share of however many chunks the
+  // plan kernel made (a count only the device knows)
+  const uint32_t grid = n_pages < (uint32_t)cus ? n_pages : (uint32_t)cus;
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
-  hipError_t e;
 #ifdef PQD_PROF
   if (!g_prof && (e = hipMalloc((void**)&g_prof, 1024 * 24 * 8)) != hipSuccess) return e;
 #endif
-  if (elem == 4) {
-    auto k = k_dict_pages_sliced<4>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
-  } else {
-    auto k = k_dict_pages_sliced<8>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
-  }
+  if (elem == 4)
+    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
+  else
+    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
 #ifdef PQD_PROF
   prof_report(grid, stream);
 #endif

@@ -101,8 +101,8 @@ __device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint3
 }
 
 // Header walk over the staged window; run by one lane.  Follows readNext() (:80-109).
-__device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg_start, uint32_t* seg_src,
-                                uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values) {
+__device__ void rle_scan_window(RleState& st, const uint32_t* win, const uint8_t* data, uint32_t* seg_start,
+                                uint32_t* seg_src, uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values) {
   uint32_t pos = st.pos;
   const int32_t base = st.window_base;
   const uint32_t wend = (uint32_t)(base + WINDOW_BYTES);  // stream offset one past the window
@@ -124,11 +124,10 @@ __device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg
           status = PQD_EOF;
           break;
         }
-        if (++nb > 10) {  // over-long varint: not produced by any writer
-          status = PQD_DECODE;
-          break;
-        }
-        uint32_t b = lds_byte(win, p - base);
+        // A header of more than five bytes is no writer's work, but the reference reads on until a
+        // byte without the continuation bit, its shifts wrapping at 32: such a header may leave the
+        // staged window, so from its sixth byte on it is read from memory.
+        uint32_t b = ++nb > 5 ? (uint32_t)data[p] : lds_byte(win, p - base);
         ++p;
         if (b & 0x80u) {
           header |= (b & 0x7Fu) << (shift & 31u);
@@ -148,7 +147,7 @@ __device__ void rle_scan_window(RleState& st, const uint32_t* win, uint32_t* seg
           break;
         }
         uint32_t value = 0;
-        for (uint32_t i = 0; i < nbytes; ++i) value |= lds_byte(win, p - base + i) << (8 * i);
+        for (uint32_t i = 0; i < nbytes; ++i) value |= (nb > 5 ? (uint32_t)data[p + i] : lds_byte(win, p - base + i)) << (8 * i);
         p += nbytes;
         pos = p;
         // a zero-count run leaves currentCount negative: the value repeats for the rest of the page
@@ -327,7 +326,7 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
     // ---- 2. header walk
     if (tid == 0) {
       st.window_base = wbase;
-      rle_scan_window(st, win, seg_start, seg_src, seg_kind, w, end, n_values);
+      rle_scan_window(st, win, d.data, seg_start, seg_src, seg_kind, w, end, n_values);
     }
     __syncthreads();
     // ---- 3. expansion

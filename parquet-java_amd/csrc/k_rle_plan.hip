@@ -22,6 +22,7 @@ namespace pqd {
 constexpr int PLAN_THREADS = 64;
 constexpr int PLAN_SLOTS = 64;       // 16-byte header blocks fetched per round, one per lane
 constexpr uint32_t PLAN_NEED = 9;    // bytes a header can need: 5 (varint) + 4 (RLE value)
+constexpr int32_t PLAN_ST_GENERIC = -1;  // walk status: this page is left to the generic kernel
 
 struct PlanState {
   uint32_t pos;       // next unread stream byte
@@ -89,8 +90,8 @@ __device__ void plan_walk(PlanState& st, const uint32_t* win, RleSeg* stage, uin
           status = PQD_EOF;
           break;
         }
-        if (++nb > 10) {  // over-long varint: no writer produces it
-          status = PQD_DECODE;
+        if (++nb > 5) {  // a header beyond five bytes may leave the fetched block: the generic kernel reads it
+          status = PLAN_ST_GENERIC;
           break;
         }
         const uint32_t b = lds_byte(win, off + (p - run_pos));
@@ -796,6 +797,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     if (tid == 0 && !st.need_round && !st.done)
       plan_walk(st, win, stage, w, end, n_values, seg_groups_cap, (uint32_t)SEG_GEN_MAX, windowed ? 1u : ~0u);
     __syncthreads();
+    if (st.status == PLAN_ST_GENERIC) fallback = true;
     const bool done = st.done != 0;
     const uint32_t vals = st.vals;
     uint32_t ns = st.nstage;

@@ -59,8 +59,16 @@ struct Scratch {
   }
 };
 
+// Everything the host-memory entry points keep per calling thread: device staging buffers and a
+// stream of the thread's own (created on first use, on the device current then).  Calls from
+// different host threads therefore never share a stream, staging memory or plan scratch.
 struct HostCtx {
   Scratch in, out, dict, descs, results;
+  hipStream_t stream = nullptr;
+  int stream_device = -1;
+  int ensure_stream(hipStream_t* s);
+  void release();
+  ~HostCtx() { release(); }
 };
 thread_local HostCtx g_ctx;
 
@@ -72,60 +80,117 @@ int check_device_available() {
 }
 
 // Device scratch of the planned RLE paths: one run-plan record per page and the chunk pool.
-// One per (device, stream): calls on one stream are ordered, calls on different streams must not
-// share it.  Grown on demand, never shrunk, released with the process.
+// One per (device, stream).  The kernels of one call (counter reset, plan, expansion / gather,
+// left-over pages) must reach the stream as one uninterrupted sequence: stream order then makes the
+// next call's reset wait for this call's last kernel.  `mu` is held by the calling thread from the
+// lookup (and a possible growth, which first drains the stream) until the last launch is enqueued,
+// so host threads that share a stream (the NULL stream included) queue up here instead of
+// interleaving their launches or freeing buffers another thread is about to use.
+// Grown on demand, never shrunk, released with the stream or the process.
 struct PlanScratch {
+  std::mutex mu;
   void* plans = nullptr;
   uint32_t cap_pages = 0;
   void* gen_pool = nullptr;    // chunk pool: chunk p for page p, the rest handed out through counters[0]
   uint32_t gen_chunks = 0;
   uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool
 };
-std::mutex g_plan_mutex;
+std::mutex g_plan_mutex;  // guards the map itself (nodes of a std::map do not move)
 std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
 
-int plan_scratch_for(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
+struct PlanLease {
+  PlanScratch* ps = nullptr;
+  std::unique_lock<std::mutex> lock;
+};
+
+// Plans for n_pages pages and a chunk pool of two chunks per page plus a shared reserve (a
+// 20000-value level page needs 1-6 chunks, a 1 M-value page about 31; a page that finds the pool
+// empty is decoded by the generic kernel).  Returns with the scratch locked.
+int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, PlanLease* lease) {
   int dev = 0;
   PQD_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_plan_mutex);
-  PlanScratch& ps = g_plan_scratch[std::make_pair(dev, (void*)stream)];
-  if (ps.cap_pages < n_pages) {
+  PlanScratch* ps;
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    ps = &g_plan_scratch[std::make_pair(dev, (void*)stream)];
+  }
+  std::unique_lock<std::mutex> lock(ps->mu);
+  const uint64_t want = (uint64_t)n_pages * 2 + 16384;
+  if (ps->cap_pages < n_pages || ps->gen_chunks < want || !ps->counters) {
     // wait for work that may still use the old buffers, then replace them
     PQD_HIP(hipStreamSynchronize(stream));
-    if (ps.plans) (void)hipFree(ps.plans);
-    ps.plans = nullptr;
-    ps.cap_pages = 0;
-    const uint32_t pages = n_pages + n_pages / 4 + 64;
-    PQD_HIP(hipMalloc(&ps.plans, (size_t)pages * sizeof(pqd::RlePagePlan)));
-    ps.cap_pages = pages;
+    if (ps->cap_pages < n_pages) {
+      if (ps->plans) (void)hipFree(ps->plans);
+      ps->plans = nullptr;
+      ps->cap_pages = 0;
+      const uint32_t pages = n_pages + n_pages / 4 + 64;
+      PQD_HIP(hipMalloc(&ps->plans, (size_t)pages * sizeof(pqd::RlePagePlan)));
+      ps->cap_pages = pages;
+    }
+    if (ps->gen_chunks < want) {
+      if (ps->gen_pool) (void)hipFree(ps->gen_pool);
+      ps->gen_pool = nullptr;
+      ps->gen_chunks = 0;
+      const uint64_t chunks = want + want / 4;
+      PQD_HIP(hipMalloc(&ps->gen_pool, (size_t)chunks * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
+      ps->gen_chunks = (uint32_t)(chunks > 0xFFFFFFFFull ? 0xFFFFFFFFull : chunks);
+    }
+    if (!ps->counters) PQD_HIP(hipMalloc((void**)&ps->counters, 256));
   }
-  *out = ps;
+  lease->ps = ps;
+  lease->lock = std::move(lock);
   return PQD_OK;
 }
 
-// The same, plus the chunk pool of the plain hybrid path: two chunks per page and a shared reserve
-// (a 20000-value level page needs 1-6 chunks, a 1 M-value page about 31; a page that finds the pool
-// empty is decoded by the generic kernel).
-int plan_scratch_general(hipStream_t stream, uint32_t n_pages, PlanScratch* out) {
-  int st = plan_scratch_for(stream, n_pages, out);
-  if (st) return st;
+// Frees the scratch kept for `stream` on any device (the stream must be idle).
+void plan_scratch_drop(void* stream) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  for (auto it = g_plan_scratch.begin(); it != g_plan_scratch.end();) {
+    if (it->first.second == stream) {
+      {
+        std::lock_guard<std::mutex> inner(it->second.mu);
+        if (it->second.plans) (void)hipFree(it->second.plans);
+        if (it->second.gen_pool) (void)hipFree(it->second.gen_pool);
+        if (it->second.counters) (void)hipFree(it->second.counters);
+      }
+      it = g_plan_scratch.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+int HostCtx::ensure_stream(hipStream_t* s) {
   int dev = 0;
   PQD_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_plan_mutex);
-  PlanScratch& ps = g_plan_scratch[std::make_pair(dev, (void*)stream)];
-  const uint64_t want = (uint64_t)n_pages * 2 + 16384;
-  if (ps.gen_chunks < want) {
-    PQD_HIP(hipStreamSynchronize(stream));
-    if (ps.gen_pool) (void)hipFree(ps.gen_pool);
-    ps.gen_pool = nullptr;
-    ps.gen_chunks = 0;
-    const uint64_t chunks = want + want / 4;
-    PQD_HIP(hipMalloc(&ps.gen_pool, (size_t)chunks * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
-    ps.gen_chunks = (uint32_t)(chunks > 0xFFFFFFFFull ? 0xFFFFFFFFull : chunks);
+  if (stream && stream_device != dev) {  // the thread moved to another device: its stream goes
+    (void)hipStreamSynchronize(stream);
+    plan_scratch_drop(stream);
+    (void)hipStreamDestroy(stream);
+    stream = nullptr;
   }
-  if (!ps.counters) PQD_HIP(hipMalloc((void**)&ps.counters, 256));
-  *out = ps;
+  if (!stream) {
+    PQD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream_device = dev;
+  }
+  *s = stream;
   return PQD_OK;
+}
+
+void HostCtx::release() {
+  for (Scratch* b : {&in, &out, &dict, &descs, &results}) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+    b->device = -1;
+  }
+  if (stream) {
+    (void)hipStreamSynchronize(stream);
+    plan_scratch_drop(stream);
+    (void)hipStreamDestroy(stream);
+    stream = nullptr;
+    stream_device = -1;
+  }
 }
 
 // Optional per-launch timing of the dictionary path (pqd_set_phase_timing): one set of four
@@ -276,19 +341,7 @@ int pqd_stream_create(void** stream) {
 int pqd_stream_destroy(void* stream) {
   if (!stream) return PQD_OK;
   PQD_HIP(hipStreamSynchronize(as_stream(stream)));
-  {  // the scratch the planned paths kept for this stream (on any device) goes with it
-    std::lock_guard<std::mutex> lock(g_plan_mutex);
-    for (auto it = g_plan_scratch.begin(); it != g_plan_scratch.end();) {
-      if (it->first.second == stream) {
-        if (it->second.plans) (void)hipFree(it->second.plans);
-        if (it->second.gen_pool) (void)hipFree(it->second.gen_pool);
-        if (it->second.counters) (void)hipFree(it->second.counters);
-        it = g_plan_scratch.erase(it);
-      } else {
-        ++it;
-      }
-    }
-  }
+  plan_scratch_drop(stream);  // the scratch the planned paths kept for this stream (on any device) goes with it
   PQD_HIP(hipStreamDestroy(as_stream(stream)));
   return PQD_OK;
 }
@@ -394,16 +447,18 @@ static int unpack_host(int bit_width, int elem, const uint8_t* in, size_t in_len
   if (n_values == 0) return PQD_OK;
   if ((st = check_device_available())) return st;
   HostCtx& c = g_ctx;
+  hipStream_t s;
+  if ((st = c.ensure_stream(&s))) return st;
   if ((st = c.in.ensure(total + 16))) return st;
   if ((st = c.out.ensure(n_values * (size_t)elem))) return st;
-  if (total) PQD_HIP(hipMemcpyAsync(c.in.p, in, total, hipMemcpyHostToDevice, nullptr));
+  if (total) PQD_HIP(hipMemcpyAsync(c.in.p, in, total, hipMemcpyHostToDevice, s));
   if (elem == 4)
-    st = pqd_unpack_i32_dev(bit_width, (const uint8_t*)c.in.p, total, (int32_t*)c.out.p, n_values, nullptr);
+    st = pqd_unpack_i32_dev(bit_width, (const uint8_t*)c.in.p, total, (int32_t*)c.out.p, n_values, s);
   else
-    st = pqd_unpack_i64_dev(bit_width, (const uint8_t*)c.in.p, total, (int64_t*)c.out.p, n_values, nullptr);
+    st = pqd_unpack_i64_dev(bit_width, (const uint8_t*)c.in.p, total, (int64_t*)c.out.p, n_values, s);
   if (st) return st;
-  PQD_HIP(hipMemcpyAsync(out, c.out.p, n_values * (size_t)elem, hipMemcpyDeviceToHost, nullptr));
-  PQD_HIP(hipStreamSynchronize(nullptr));
+  PQD_HIP(hipMemcpyAsync(out, c.out.p, n_values * (size_t)elem, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
   return PQD_OK;
 }
 
@@ -430,9 +485,10 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         // 1. header walk of every page -> chunks of run segments in the pool
         // 2. expansion of all chunks (workgroups take chunks from a counter)
         // 3. generic kernel for the pages the plan left over
-        PlanScratch ps;
-        int st = plan_scratch_general(s, n_pages, &ps);
+        PlanLease lease;  // holds the scratch until the last launch below is enqueued
+        int st = plan_scratch_acquire(s, n_pages, &lease);
         if (st) return st;
+        PlanScratch& ps = *lease.ps;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4, s));
@@ -448,9 +504,10 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         // 1. header walk of every page (one wave per page) -> chunks of run segments in the pool
         // 2. expansion + sliced LDS gather, chunk by chunk
         // 3. generic kernel for the pages the plan left over
-        PlanScratch ps;
-        int st = plan_scratch_general(s, n_pages, &ps);
+        PlanLease lease;  // holds the scratch until the last launch below is enqueued
+        int st = plan_scratch_acquire(s, n_pages, &lease);
         if (st) return st;
+        PlanScratch& ps = *lease.ps;
         PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
         if ((st = phase_mark(0, s))) return st;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
@@ -520,33 +577,61 @@ int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint3
   return PQD_OK;
 }
 
-int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result) {
-  if (!desc || !result) return fail(PQD_BAD_ARG, "null descriptor / result");
+int pqd_decode_page_flat(int encoding, int elem_size, int bit_width, uint32_t flags, const uint8_t* data,
+                         uint32_t data_len, uint32_t num_values, const void* dict, uint32_t dict_len, void* out,
+                         pqd_page_result* result) {
+  if (!result) return fail(PQD_BAD_ARG, "null result");
+  if (encoding < 0 || encoding > 255 || elem_size < 0 || elem_size > 255 || bit_width < 0 || bit_width > 255 || flags > 255u)
+    return fail(PQD_BAD_ARG, "encoding / element size / bit width / flags out of range");
   int st = check_device_available();
   if (st) return st;
   HostCtx& c = g_ctx;
-  pqd_page_desc d = *desc;
-  const size_t out_bytes = (size_t)d.num_values * (d.elem_size ? d.elem_size : 1);
-  if (d.data_len && !d.data) return fail(PQD_BAD_ARG, "null page data");
-  if (out_bytes && !d.out) return fail(PQD_BAD_ARG, "null output");
-  if ((st = c.in.ensure((size_t)d.data_len + 16))) return st;
+  hipStream_t s;
+  if ((st = c.ensure_stream(&s))) return st;
+  pqd_page_desc d{};
+  d.data_len = data_len;
+  d.num_values = num_values;
+  d.dict_len = dict_len;
+  d.encoding = (uint8_t)encoding;
+  d.elem_size = (uint8_t)elem_size;
+  d.bit_width = (uint8_t)bit_width;
+  d.flags = (uint8_t)flags;
+  const size_t out_bytes = (size_t)num_values * (elem_size ? (size_t)elem_size : 1);
+  if (data_len && !data) return fail(PQD_BAD_ARG, "null page data");
+  if (out_bytes && !out) return fail(PQD_BAD_ARG, "null output");
+  if ((st = c.in.ensure((size_t)data_len + 16))) return st;
   if ((st = c.out.ensure(out_bytes + 16))) return st;
-  if (d.data_len) PQD_HIP(hipMemcpyAsync(c.in.p, d.data, d.data_len, hipMemcpyHostToDevice, nullptr));
+  if (data_len) PQD_HIP(hipMemcpyAsync(c.in.p, data, data_len, hipMemcpyHostToDevice, s));
   d.data = (const uint8_t*)c.in.p;
-  void* host_out = d.out;
   d.out = c.out.p;
-  if (d.encoding == PQD_ENC_RLE_DICTIONARY) {
-    const size_t dict_bytes = (size_t)d.dict_len * d.elem_size;
-    if (dict_bytes && !d.dict) return fail(PQD_BAD_ARG, "null dictionary");
+  if (encoding == PQD_ENC_RLE_DICTIONARY) {
+    const size_t dict_bytes = (size_t)dict_len * (size_t)elem_size;
+    if (dict_bytes && !dict) return fail(PQD_BAD_ARG, "null dictionary");
     if ((st = c.dict.ensure(dict_bytes + 16))) return st;
-    if (dict_bytes) PQD_HIP(hipMemcpyAsync(c.dict.p, d.dict, dict_bytes, hipMemcpyHostToDevice, nullptr));
+    if (dict_bytes) PQD_HIP(hipMemcpyAsync(c.dict.p, dict, dict_bytes, hipMemcpyHostToDevice, s));
     d.dict = c.dict.p;
   }
-  st = pqd_decode_pages(&d, result, 1, nullptr);
+  st = pqd_decode_pages(&d, result, 1, s);
   if (st) return st;
-  const size_t valid = (size_t)result->values_written * d.elem_size;
-  if (valid) PQD_HIP(hipMemcpyAsync(host_out, c.out.p, valid, hipMemcpyDeviceToHost, nullptr));
-  PQD_HIP(hipStreamSynchronize(nullptr));
+  const size_t valid = (size_t)result->values_written * (size_t)elem_size;
+  if (valid) PQD_HIP(hipMemcpyAsync(out, c.out.p, valid, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  return PQD_OK;
+}
+
+int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result) {
+  if (!desc || !result) return fail(PQD_BAD_ARG, "null descriptor / result");
+  return pqd_decode_page_flat(desc->encoding, desc->elem_size, desc->bit_width, desc->flags, desc->data, desc->data_len,
+                              desc->num_values, desc->dict, desc->dict_len, desc->out, result);
+}
+
+int pqd_thread_release(void) {
+  g_ctx.release();
+  PhaseTimer& t = g_phase;
+  for (auto e : t.events) (void)hipEventDestroy(e);
+  t.events.clear();
+  t.used = 0;
+  t.device = -1;
   return PQD_OK;
 }
 
@@ -682,6 +767,8 @@ int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t p
   int st = check_device_available();
   if (st) return st;
   HostCtx& c = g_ctx;
+  hipStream_t s;
+  if ((st = c.ensure_stream(&s))) return st;
   // device staging: page | views (in `out`) | offsets + bytes (in `dict`) | descriptors + results
   const size_t views_bytes = (size_t)num_values * 8, offs_bytes = ((size_t)num_values + 1) * 4;
   const size_t offs_padded = (offs_bytes + 15) & ~(size_t)15;
@@ -690,7 +777,7 @@ int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t p
   if ((st = c.dict.ensure(offs_padded + bytes_capacity + 16))) return st;
   if ((st = c.descs.ensure(sizeof(pqd_page_desc) + sizeof(pqd_binary_page_desc)))) return st;
   if ((st = c.results.ensure(2 * sizeof(pqd_page_result)))) return st;
-  if (page_len) PQD_HIP(hipMemcpyAsync(c.in.p, page, page_len, hipMemcpyHostToDevice, nullptr));
+  if (page_len) PQD_HIP(hipMemcpyAsync(c.in.p, page, page_len, hipMemcpyHostToDevice, s));
   pqd_page_desc d{};
   d.data = (const uint8_t*)c.in.p;
   d.out = c.out.p;
@@ -701,7 +788,7 @@ int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t p
   d.encoding = PQD_ENC_RLE_DICTIONARY;
   d.elem_size = 8;
   pqd_page_result ids_result{};
-  if ((st = pqd_decode_pages(&d, &ids_result, 1, nullptr))) return st;
+  if ((st = pqd_decode_pages(&d, &ids_result, 1, s))) return st;
   pqd_binary_page_desc b{};
   b.views = (const uint64_t*)c.out.p;
   b.dict_bytes = dict->bytes;
@@ -712,15 +799,15 @@ int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t p
   b.bytes_capacity = bytes_capacity;
   pqd_binary_page_desc* d_b = (pqd_binary_page_desc*)((uint8_t*)c.descs.p + sizeof(pqd_page_desc));
   pqd_page_result* d_r = (pqd_page_result*)c.results.p + 1;
-  PQD_HIP(hipMemcpyAsync(d_b, &b, sizeof b, hipMemcpyHostToDevice, nullptr));
-  if ((st = pqd_binary_materialize_dev(d_b, d_r, 1, nullptr))) return st;
+  PQD_HIP(hipMemcpyAsync(d_b, &b, sizeof b, hipMemcpyHostToDevice, s));
+  if ((st = pqd_binary_materialize_dev(d_b, d_r, 1, s))) return st;
   pqd_page_result bin_result{};
-  PQD_HIP(hipMemcpyAsync(&bin_result, d_r, sizeof bin_result, hipMemcpyDeviceToHost, nullptr));
-  PQD_HIP(hipStreamSynchronize(nullptr));
-  PQD_HIP(hipMemcpyAsync(offsets, b.offsets, ((size_t)bin_result.values_written + 1) * 4, hipMemcpyDeviceToHost, nullptr));
+  PQD_HIP(hipMemcpyAsync(&bin_result, d_r, sizeof bin_result, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  PQD_HIP(hipMemcpyAsync(offsets, b.offsets, ((size_t)bin_result.values_written + 1) * 4, hipMemcpyDeviceToHost, s));
   if (bin_result.bytes_consumed)
-    PQD_HIP(hipMemcpyAsync(bytes, b.bytes, bin_result.bytes_consumed, hipMemcpyDeviceToHost, nullptr));
-  PQD_HIP(hipStreamSynchronize(nullptr));
+    PQD_HIP(hipMemcpyAsync(bytes, b.bytes, bin_result.bytes_consumed, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
   result->status = bin_result.status != PQD_OK ? bin_result.status : ids_result.status;
   result->values_written = bin_result.values_written;
   result->bytes_consumed = ids_result.bytes_consumed;

@@ -244,3 +244,116 @@ def test_gpu_materialize_garbage_views(orc):
         total = int(ln.sum())
         cases.append((views, dict_bytes, int(rng.choice([total, total // 2, total + 5, 0]))))
     check_pages(gh, orc, cases)
+
+
+# ------------------------------------------------------------------------------- fixed-width dictionaries
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_name,dtype", [("TYPE_INT32", np.int32), ("TYPE_INT64", np.int64),
+                                             ("TYPE_FLOAT", np.float32), ("TYPE_DOUBLE", np.float64)])
+def test_gpu_fixed_width_dictionary_handles(orc, dict_path, type_name, dtype):
+    """pqd_dict_create for INT32 / INT64 / FLOAT / DOUBLE (PlainValuesDictionary.PlainIntegerDictionary,
+    PlainLongDictionary, PlainFloatDictionary, PlainDoubleDictionary: PlainValuesDictionary.java:139-346):
+    the dictionary page body is dictionarySize little-endian values; pages decoded through the handle's
+    device array equal the oracle's DictionaryValuesReader, NaN payloads and -0.0 included
+    (TestDictionary.java:475-505)."""
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(21)
+    elem = np.dtype(dtype).itemsize
+    for n_dict in (1, 50, 4097, 65536):
+        raw = rng.integers(0, 256, n_dict * elem, dtype=np.uint8)  # any bit pattern: NaNs of every payload among them
+        dic = raw.view(dtype).copy()
+        if np.issubdtype(dtype, np.floating) and n_dict >= 50:
+            bits = dic.view(np.uint32 if elem == 4 else np.uint64)
+            bits[:4] = [0x7FC00000, 0x7FC00001, 0xFFC00000, 0x80000000] if elem == 4 else \
+                [0x7FF8000000000000, 0x7FF8000000000001, 0xFFF8000000000000, 0x8000000000000000]
+        page = dic.view(np.uint8)
+        handle = C.c_void_p()
+        st = pq.lib.pqd_dict_create(getattr(pq, type_name), 0, page.ctypes.data_as(C.c_void_p), page.size, n_dict, C.byref(handle))
+        assert st == 0
+        info = pq.DictInfo()
+        assert pq.lib.pqd_dict_get(handle, C.byref(info)) == 0
+        assert info.n_entries == n_dict and info.elem_size == elem and not info.bytes and info.bytes_len == 0
+        assert info.physical_type == getattr(pq, type_name)
+        # the device array holds the page's values
+        back = np.zeros(n_dict * elem, np.uint8)
+        pq.check(pq.lib.pqd_memcpy_d2h(back.ctypes.data_as(C.c_void_p), info.entries, back.size, None))
+        torch.cuda.synchronize()
+        assert (back == page).all()
+        # pages decoded against it (device-resident batch, the handle's array as `dict`)
+        datas, ids_all = [], []
+        for n in (1, 777, 20000):
+            ids = rng.integers(0, n_dict, n).astype(np.int32)
+            ids[: min(n, 4)] = np.arange(min(n, 4)) % n_dict
+            ids_all.append(ids)
+            datas.append(orc.dict_encode_ids(ids, n_dict))
+        d_blob = gh.to_dev(np.concatenate(datas))
+        d_out = torch.zeros(sum(i.size for i in ids_all) * elem, dtype=torch.uint8, device=gh.dev())
+        descs, pos, opos = [], 0, 0
+        for ids, d in zip(ids_all, datas):
+            descs.append(dict(data=d_blob.data_ptr() + pos, out=d_out.data_ptr() + opos, dict=info.entries, data_len=d.size,
+                              num_values=ids.size, dict_len=info.n_entries, encoding=pq.ENC_RLE_DICTIONARY, elem_size=elem))
+            pos += d.size
+            opos += ids.size * elem
+        results = (pq.PageResult * len(descs))()
+        assert pq.lib.pqd_decode_pages(pq.make_descs(descs), results, len(descs), None) == 0
+        got = d_out.cpu().numpy()
+        opos = 0
+        for ids, d, r in zip(ids_all, datas, results):
+            ost, ovals = orc.dict_decode(d, dic, ids.size)
+            assert r.status == ost == 0 and r.values_written == ids.size
+            assert (got[opos:opos + ids.size * elem] == ovals.view(np.uint8)).all()  # bit patterns, not float compares
+            opos += ids.size * elem
+        assert pq.lib.pqd_dict_destroy(handle) == 0
+    # a page shorter than dictionarySize values: the Java constructor runs off the page
+    # (PlainValuesReader.readInteger -> ParquetDecodingException, PlainValuesReader.java:62-68)
+    short = np.zeros(10 * elem - 1, np.uint8)
+    handle = C.c_void_p()
+    assert pq.lib.pqd_dict_create(getattr(pq, type_name), 0, short.ctypes.data_as(C.c_void_p), short.size, 10, C.byref(handle)) == pq.DECODE
+    assert not handle.value
+    # an empty dictionary is legal; a page that refers to it fails at its first value
+    assert pq.lib.pqd_dict_create(getattr(pq, type_name), 0, None, 0, 0, C.byref(handle)) == 0
+    assert pq.lib.pqd_dict_get(handle, C.byref(info)) == 0 and info.n_entries == 0
+    assert pq.lib.pqd_dict_destroy(handle) == 0
+    assert pq.lib.pqd_dict_create(99, 0, short.ctypes.data_as(C.c_void_p), short.size, 1, C.byref(handle)) == pq.BAD_ARG
+
+
+@pytest.mark.gpu
+def test_gpu_binary_dictionary_of_64k_entries(orc, dict_path):
+    """The BINARY column of the 64 Ki-entry configuration: entries of 4-12 bytes (a 768 KiB dictionary
+    page), ids -> views -> offsets + bytes, against the oracle's materialisation."""
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(31)
+    n_dict = 65536
+    lens = rng.integers(4, 13, n_dict)
+    blob = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    ends = np.cumsum(lens)
+    values = [blob[e - l:e].tobytes() for e, l in zip(ends, lens)]
+    page = orc.binary_dict_page(values)
+    assert 700_000 < page.size < 1 << 20
+    st, views = orc.binary_dict_views(page, n_dict)
+    assert st == 0
+    pages, ids_all = [], []
+    for p in range(12):
+        n = 20000 if p < 10 else int(rng.integers(1, 20000))
+        ids = rng.integers(0, n_dict, n).astype(np.int32)
+        if p == 3:
+            ids = np.sort(ids)
+        if p == 4:
+            ids[:] = n_dict - 1  # the dictionary's last entry, as one RLE run
+        ids_all.append(ids)
+        pages.append(gh.Page(orc.dict_encode_ids(ids, n_dict), n, pq.ENC_RLE_DICTIONARY, 8, dictionary=views))
+    res = gh.decode_pages(pages)
+    cases = []
+    for ids, (st, written, _, out, _) in zip(ids_all, res):
+        got = out.view(np.uint64)
+        assert st == 0 and written == ids.size and (got == views[ids]).all()
+        cases.append((got, page, int(lens[ids].sum())))
+    check_pages(gh, orc, cases)
+    st, written, nbytes, offsets, data, _ = gh.materialize_binary(cases[:1])[0]
+    ids = ids_all[0]
+    assert all(data[offsets[i]:offsets[i + 1]].tobytes() == values[ids[i]] for i in range(0, ids.size, 501))

@@ -117,6 +117,16 @@ def test_rle_known_answer_and_quirks(gpu, orc, rle_path):
         (0, bytes([20]), 10, 0), (0, bytes([5]), 16, 0), (0, bytes([5]), 17, 0),  # width 0
         (7, bytes([0x80, 0x80, 0x80]), 4, 0),  # varint runs off the end
         (4, bytes([3, 0x21]), 8, 0),  # packed run cut after one byte of four
+        # headers longer than a 32-bit varint needs: BytesUtils.readUnsignedVarInt (BytesUtils.java:202-211)
+        # reads on until a byte without the continuation bit, its shifts wrapping at 32
+        (8, bytes([0x94, 0x80, 0x80, 0x80, 0x00, 9]), 10, 0),  # five bytes, still canonical: count 10
+        (8, bytes([0x94] + [0x80] * 5 + [0x00, 9]), 10, 0),  # seven bytes, same value
+        (8, bytes([0x80] * 5 + [0x05, 9]), 40, 0),  # byte 6 lands at shift 35 & 31 = 3: header 40, count 20
+        (8, bytes([0x94] + [0x80] * 10 + [0x00, 9, 4, 3]), 12, 0),  # twelve bytes, then a second run
+        (3, bytes([0x83] + [0x80] * 11 + [0x00, 0x88, 0xC6, 0xFA]), 8, 0),  # a bit-packed run behind a 13-byte header
+        (8, bytes([0x94] + [0x80] * 300 + [0x01, 9]), 15, 0),  # 302 bytes: shift 7 * 301 & 31 = 27: count 10 + (1 << 26)
+        (8, bytes([2, 5]) + bytes([0x90] + [0x80] * 40 + [0x00, 6]), 9, 0),  # a normal run first, then an over-long header
+        (8, bytes([0x94] + [0x80] * 20), 4, 0),  # over-long and runs off the end
     ]
     body = orc.rle_encode(2, [1, 2, 3, 0] * 10)
     pre = struct.pack("<i", body.size) + bytes(body) + b"\xAA\xBB"

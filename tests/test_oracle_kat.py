@@ -220,6 +220,15 @@ def test_rle_value_not_masked_and_quirks(orc):
     # multi-byte varint header: 200 values
     st, out, _ = orc.rle_decode(1, bytes([0x90, 0x03, 1]), 200)
     assert st == orc.OK and out.tolist() == [1] * 200
+    # headers longer than five bytes (BytesUtils.readUnsignedVarInt, BytesUtils.java:202-211): the loop
+    # reads until a byte without the continuation bit and Java shifts an int by (i & 31).  Worked by
+    # hand: 0x94 then continuation bytes of zero payload then 0x00 is still 20 = RLE run of 10; five
+    # 0x80 and then 0x05 puts the 5 at shift 35 & 31 = 3: header 40 = RLE run of 20.
+    st, out, used = orc.rle_decode(8, bytes([0x94] + [0x80] * 5 + [0x00, 9]), 10)
+    assert st == orc.OK and out.tolist() == [9] * 10 and used == 8
+    st, out, used = orc.rle_decode(8, bytes([0x80] * 5 + [0x05, 9]), 40)
+    assert st == orc.PAST_END and out.tolist() == [9] * 20 and used == 7
+    assert orc.rle_decode(8, bytes([0x94] + [0x80] * 20), 4)[0] == orc.EOF
 
 
 def test_rle_prefixed(orc):
