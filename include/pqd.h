@@ -173,6 +173,22 @@ int pqd_unpack_i64_dev(int bit_width, const uint8_t* in, size_t in_len, int64_t*
 int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,
                          int elem_size, void* stream);
 /*
+ * pqd_decode_pages_dev for callers that cannot allocate device memory while they run: code under
+ * HIP graph capture, serving loops that must not touch the allocator, harnesses that forbid it.
+ * (No counterpart in the reference: the JVM allocates per run, RunLengthBitPackingHybridDecoder.java:94-99.)
+ * Same arguments, same results, same kernels; the scratch of the planned hybrid / dictionary paths
+ * (chunk pool, plan records, counters: 16 MiB + 16.25 KiB) lives in a device array that is part of
+ * the library image, one copy per GPU, instead of buffers the library allocates.  It calls no
+ * hipMalloc / hipFree.  Limits: at most 2048 pages per call (PQD_BAD_ARG beyond that; pages whose
+ * runs outgrow the 8192-chunk pool are decoded by the generic kernel, as in pqd_decode_pages_dev).
+ * All calls on one GPU share that GPU's array: a call may be enqueued only when the previous
+ * call's work on that GPU has finished or is ahead of it on the same stream; calls that overlap on
+ * one GPU (different streams) race.  Encodings that use no scratch (DELTA_BINARY_PACKED,
+ * BYTE_STREAM_SPLIT, BIT_PACKED) are passed through to pqd_decode_pages_dev.
+ */
+int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,
+                                 int elem_size, void* stream);
+/*
  * Host-side batch: `descs`/`results` are HOST arrays, but data/out/dict are still device pointers.
  * Groups the pages by encoding class, uploads the descriptors, launches, downloads the results and
  * synchronises `stream`.

@@ -76,6 +76,7 @@ EXPORTS = {
     "pqd_unpack_i64": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
     "pqd_unpack_i64_dev": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int),
     "pqd_decode_pages_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "pqd_decode_pages_dev_noalloc": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "pqd_decode_pages": ([C.POINTER(PageDesc), C.POINTER(PageResult), C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_page": ([C.POINTER(PageDesc), C.POINTER(PageResult)], C.c_int),
     "pqd_decode_page_flat": ([C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,

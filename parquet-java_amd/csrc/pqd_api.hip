@@ -15,6 +15,18 @@
 #include "pqd_kernels.hpp"
 #include "pqd_rle_plan.hpp"
 
+// Scratch of pqd_decode_pages_dev_noalloc: a chunk pool, one plan record per page and the counter
+// block of the planned hybrid / dictionary paths, in a file-scope device array (every GPU the
+// library runs on holds its own copy until the process ends).  Host code never uses the array's
+// name as an address: the per-device address comes from hipGetSymbolAddress (noalloc_scratch).
+constexpr uint32_t NOALLOC_MAX_PAGES = 2048;
+constexpr uint32_t NOALLOC_POOL_CHUNKS = 8192;  // chunk p for page p, the rest shared
+constexpr size_t NOALLOC_POOL_BYTES = (size_t)NOALLOC_POOL_CHUNKS * pqd::SEG_CHUNK * sizeof(pqd::RleSeg);
+constexpr size_t NOALLOC_PLANS_BYTES = (size_t)NOALLOC_MAX_PAGES * sizeof(pqd::RlePagePlan);
+constexpr size_t NOALLOC_COUNTER_BYTES = 256;
+constexpr size_t NOALLOC_BYTES = NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES + NOALLOC_COUNTER_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -193,6 +205,26 @@ void HostCtx::release() {
   }
 }
 
+// Device address of `scratch` on the current device (looked up once per device, with that device
+// current: each GPU has its own copy of the array at its own address).
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_noalloc_mutex;  // guards the table; also held while a call's launches are enqueued
+unsigned char* g_noalloc_ptr[NOALLOC_MAX_DEVICES];
+
+int noalloc_scratch(unsigned char** out) {
+  int dev = 0;
+  PQD_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(PQD_BAD_ARG, "device index beyond the library's table");
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    PQD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(PQD_HIP_ERROR, "hipGetSymbolAddress returned no address for the scratch array");
+    g_noalloc_ptr[dev] = static_cast<unsigned char*>(p);
+  }
+  *out = g_noalloc_ptr[dev];
+  return PQD_OK;
+}
+
 // Optional per-launch timing of the dictionary path (pqd_set_phase_timing): one set of four
 // events per timed call, kept until pqd_phase_ms_mean reads them.
 struct PhaseTimer {
@@ -296,6 +328,11 @@ int pqd_init(int device) {
   PQD_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(PQD_NO_DEVICE, "device is not gfx950");
   PQD_HIP(hipSetDevice(device));
+  {  // the address of this device's copy of the no-allocation scratch
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    unsigned char* p;
+    if ((st = noalloc_scratch(&p))) return st;
+  }
   return PQD_OK;
 }
 
@@ -534,6 +571,39 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
     default:
       return fail(PQD_BAD_ARG, "unknown encoding");
   }
+}
+
+int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,
+                                 int elem_size, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  if (encoding != PQD_ENC_RLE && encoding != PQD_ENC_RLE_DICTIONARY)  // the other encodings use no scratch at all
+    return pqd_decode_pages_dev(descs, results, n_pages, encoding, elem_size, stream);
+  if (n_pages > NOALLOC_MAX_PAGES)
+    return fail(PQD_BAD_ARG, "pqd_decode_pages_dev_noalloc: more than 2048 pages in one call (split the batch, or use pqd_decode_pages_dev)");
+  if (encoding == PQD_ENC_RLE && elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_RLE produces 4-byte values");
+  if (encoding == PQD_ENC_RLE_DICTIONARY && elem_size != 4 && elem_size != 8)
+    return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");
+  hipStream_t s = as_stream(stream);
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);  // one launch sequence at a time reaches the streams
+  unsigned char* base;
+  int st = noalloc_scratch(&base);
+  if (st) return st;
+  void* pool = base;
+  void* plans = base + NOALLOC_POOL_BYTES;
+  uint32_t* counters = reinterpret_cast<uint32_t*>(base + NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES);
+  const uint32_t pool_chunks = usable_pool_chunks(NOALLOC_POOL_CHUNKS);
+  const bool dict = encoding == PQD_ENC_RLE_DICTIONARY;
+  // the array keeps the last call's contents: the counters must start at zero; plans and chunks are
+  // written by the plan kernel before anything reads them
+  PQD_HIP(hipMemsetAsync(counters, 0, NOALLOC_COUNTER_BYTES, s));
+  PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, s));
+  if (dict)
+    PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, s));
+  else
+    PQD_HIP(pqd::launch_rle_expand(pool, pool_chunks, counters, n_pages, s));
+  PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s));
+  return PQD_OK;
 }
 
 int pqd_decode_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream) {
