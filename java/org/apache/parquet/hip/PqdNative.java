@@ -42,25 +42,33 @@ public final class PqdNative {
     return LINKER.downcallHandle(LIB.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), fd, opts);
   }
 
-  // heap int[] / byte[] are passed without a copy: Linker.Option.critical(true) lets a downcall take
-  // MemorySegment.ofArray(...) (the FFM counterpart of JNI GetPrimitiveArrayCritical)
+  // Heap int[] / byte[] can be handed to a downcall only as DIRECT arguments of a handle linked with
+  // Linker.Option.critical(true) (MemorySegment.ofArray(...), the FFM counterpart of JNI
+  // GetPrimitiveArrayCritical).  The three entry points below take every buffer as an argument of its
+  // own for that reason; they block until the device has answered (tens of microseconds per page).
   static final MethodHandle UNPACK_I32 = h("pqd_unpack_i32",
       FunctionDescriptor.of(JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG), Linker.Option.critical(true));
   static final MethodHandle UNPACK_I64 = h("pqd_unpack_i64",
       FunctionDescriptor.of(JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, JAVA_LONG), Linker.Option.critical(true));
-  static final MethodHandle DECODE_PAGE = h("pqd_decode_page",
-      FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS), Linker.Option.critical(true));
+  // pqd_decode_page_flat(encoding, elem_size, bit_width, flags, data, data_len, num_values, dict, dict_len, out, result)
+  static final MethodHandle DECODE_PAGE_FLAT = h("pqd_decode_page_flat",
+      FunctionDescriptor.of(JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT,
+          ADDRESS, ADDRESS), Linker.Option.critical(true));
+  // Pointers INSIDE a struct cannot be heap arrays, and calls that allocate or copy large buffers
+  // are not short: these handles are linked without `critical` and take native / direct-buffer memory.
+  static final MethodHandle DECODE_PAGE = h("pqd_decode_page", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
   static final MethodHandle DECODE_PAGES = h("pqd_decode_pages",
       FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
   // dictionaries: pqd_dict_create(physical_type, type_length, page, page_len, n_entries, &dict) replaces
   // Encoding.PLAIN.initDictionary; pqd_decode_binary_page replaces the readBytes() loop of a
   // DictionaryValuesReader over a PlainBinaryDictionary (offsets[n+1] + bytes come back)
   static final MethodHandle DICT_CREATE = h("pqd_dict_create",
-      FunctionDescriptor.of(JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS), Linker.Option.critical(true));
+      FunctionDescriptor.of(JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
   static final MethodHandle DICT_DESTROY = h("pqd_dict_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
   static final MethodHandle DECODE_BINARY_PAGE = h("pqd_decode_binary_page",
-      FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS),
-      Linker.Option.critical(true));
+      FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+  // gives back the calling thread's stream and staging buffers (executors that retire threads)
+  static final MethodHandle THREAD_RELEASE = h("pqd_thread_release", FunctionDescriptor.of(JAVA_INT));
   static final MethodHandle DEVICE_COUNT = h("pqd_device_count", FunctionDescriptor.of(JAVA_INT));
   static final MethodHandle INIT = h("pqd_init", FunctionDescriptor.of(JAVA_INT, JAVA_INT));
   static final MethodHandle LAST_ERROR = h("pqd_last_error", FunctionDescriptor.of(ADDRESS));

@@ -113,8 +113,11 @@ def flatten(col):
         rows = arr.to_pylist()
         leaf = [x for r in rows if r is not None for x in r]
         return leaf, rows
+    present = arr.is_valid().to_numpy(zero_copy_only=False).tolist()
+    if pa.types.is_floating(arr.type) or pa.types.is_integer(arr.type):
+        return arr.drop_null().to_numpy(zero_copy_only=False), present  # bit patterns survive (a Python float would quiet a signalling NaN)
     vals = arr.to_pylist()
-    return [v for v in vals if v is not None], [v is not None for v in vals]
+    return [v for v in vals if v is not None], present
 
 
 def b64(raw):

@@ -1,0 +1,362 @@
+// Exploration microbenchmark (not part of the product): out[i] = dict[id[i]] for a 65536-entry
+// dictionary of 8-byte values that does not fit LDS, ids as uint16 in HBM (100 M of them).
+//   A. "slices": the dictionary streams through LDS in 64 KiB slices of whole entries; a pass tests
+//      every id against the slice's range (subtract, compare, conditional 8-byte LDS read).
+//   B. "planes": the dictionary is stored plane-major (plane p = bytes 2p, 2p+1 of every entry, i.e.
+//      four arrays of 65536 x 2 bytes); a pass brings half a plane (32768 entries x 2 bytes = 64 KiB)
+//      into the LDS buffer of that half, so the LDS address of an entry is always 2 * id, and a lookup
+//      is ONE 2-byte LDS read into the right half of a result register under a lane mask that was
+//      computed once per value (id < 32768): no subtract, no compare, no branch per pass.
+// Both sweep in alternating order (the two passes a batch ends with are the two the next one starts
+// with), double-buffer the LDS-DMA the same way and prefetch the next batch's ids.
+//   hipcc --offload-arch=gfx950 -O3 -o plane_bench plane_bench.hip && ./plane_bench
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define LDSP __attribute__((address_space(3)))
+#define GLBP __attribute__((address_space(1)))
+
+constexpr int THREADS = 1024;
+constexpr int WAVES = THREADS / 64;
+constexpr uint32_t BUF = 65536;
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ void dma16(const void* gbase, uint32_t goff, uint32_t lds_base) {
+  const uint64_t g = (uint64_t)(uintptr_t)gbase;
+  const uint64_t gs = ((uint64_t)uni((uint32_t)(g >> 32)) << 32) | uni((uint32_t)g);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(goff), "s"(gs) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wg_barrier_keep() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// 64 KiB from src into the LDS buffer at byte address lds_buf, all 16 waves
+__device__ __forceinline__ void load_64k(const uint8_t* src, uint32_t lds_buf, uint32_t wave, uint32_t lane) {
+#pragma unroll
+  for (int i = 0; i < (int)(BUF / 16 / THREADS); ++i) {
+    const uint32_t piece0 = ((uint32_t)i * WAVES + wave) * 64;
+    dma16(src + (size_t)piece0 * 16, lane * 16, lds_buf + piece0 * 16);
+  }
+}
+
+__device__ __forceinline__ void store_nt(uint64_t* o, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  u32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
+}
+
+// ---------------------------------------------------------------------------------------------
+// A. slices of whole entries
+template <int R, int SKEL>
+__global__ __launch_bounds__(THREADS) void k_slices(const uint16_t* __restrict__ ids, const uint64_t* __restrict__ dict,
+                                                    uint64_t* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSP uint8_t*)lds4;
+  constexpr int UNITS = R / 4;
+  constexpr uint32_t P = 8;
+  const uint32_t tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63u;
+  const size_t batch = (size_t)THREADS * R;
+  const uint8_t* dbytes = reinterpret_cast<const uint8_t*>(dict);
+  bool descending = false;
+  load_64k(dbytes, lds0, wave, lane);
+  load_64k(dbytes + BUF, lds0 + BUF, wave, lane);
+  u32x2 nxt[UNITS];
+  size_t b0 = (size_t)blockIdx.x * batch;
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) {
+    const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
+    nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+  }
+  wg_barrier();
+  for (; b0 < n; b0 += (size_t)gridDim.x * batch) {
+    uint32_t id[R];
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      id[4 * k] = (nxt[k].x & 0xFFFF) * 8;
+      id[4 * k + 1] = (nxt[k].x >> 16) * 8;
+      id[4 * k + 2] = (nxt[k].y & 0xFFFF) * 8;
+      id[4 * k + 3] = (nxt[k].y >> 16) * 8;
+    }
+    const size_t nb0 = b0 + (size_t)gridDim.x * batch;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = nb0 / 4 + (size_t)k * THREADS + tid;
+      nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+    }
+    uint32_t vlo[R], vhi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
+    // slice s lives in buffer s & 1; the two slices the last batch ended with are resident
+    for (uint32_t i = 0; i < P; ++i) {
+      const uint32_t s = descending ? P - 1 - i : i;
+      const uint32_t curb = s & 1u;
+      if (i >= 2) {  // slice s is not resident: it was requested two passes ago into this buffer's twin... see below
+      }
+      // wait for this pass's slice (requested one pass ago) and for everybody to be done with the other buffer
+      if (i == 0)
+        wg_barrier_keep<UNITS>();
+      else
+        wg_barrier();
+      // request the slice of the next pass into the other buffer (passes 0 and 1 find theirs resident)
+      if (i >= 1 && i + 1 < P) {
+        const uint32_t nx = descending ? s - 1 : s + 1;
+        load_64k(dbytes + (size_t)nx * BUF, lds0 + (nx & 1u) * BUF, wave, lane);
+      }
+      if (SKEL) continue;
+      const LDSP uint8_t* buf = (const LDSP uint8_t*)(uintptr_t)(lds0 + curb * BUF);
+      const uint32_t base = s * BUF;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t a = id[r] - base;
+        if (a < BUF) {
+          const u32x2 t = *(const LDSP u32x2*)(buf + a);
+          vlo[r] = t.x;
+          vhi[r] = t.y;
+        }
+      }
+    }
+    descending = !descending;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
+      if (u * 4 < n) {
+        store_nt(out + u * 4, vlo[4 * k], vhi[4 * k], vlo[4 * k + 1], vhi[4 * k + 1]);
+        store_nt(out + u * 4 + 2, vlo[4 * k + 2], vhi[4 * k + 2], vlo[4 * k + 3], vhi[4 * k + 3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B. planes.  One lookup: 2 bytes of plane PL (0..3) of entry id into the matching half of vlo / vhi,
+// for the lanes in `mask` (HALF 0) or outside it (HALF 1).  EXEC is all ones on entry and on exit.
+template <int PL, int HALF>
+__device__ __forceinline__ void lookup(uint32_t& vlo, uint32_t& vhi, uint32_t addr, uint64_t mask) {
+  if (PL == 0) {
+    if (HALF == 0)
+      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
+    else
+      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
+  } else if (PL == 1) {
+    if (HALF == 0)
+      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
+    else
+      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
+  } else if (PL == 2) {
+    if (HALF == 0)
+      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+    else
+      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+  } else {
+    if (HALF == 0)
+      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+    else
+      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+  }
+}
+
+// Pass Q of a sweep (Q = 0..7 in sweep order; DESC: the sweep runs from plane 3 down).  Plane-half
+// (p, h) always lives in buffer h, at LDS address h * 64 KiB, so an entry's address is 2 * id.
+template <int R, int Q, bool DESC, int SKEL>
+__device__ __forceinline__ void plane_pass(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                           uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
+                                           const uint64_t (&mask)[R]) {
+  constexpr int S = DESC ? 7 - Q : Q;  // plane-half index: plane S >> 1, half S & 1
+  constexpr int PL = S >> 1, HALF = S & 1;
+  if (Q == 0)
+    wg_barrier_keep<R / 4>();  // the id prefetch stays in flight
+  else
+    wg_barrier();
+  if (Q >= 1 && Q + 1 < 8) {  // passes 0 and 1 find their plane-halves resident
+    constexpr int NX = DESC ? S - 1 : S + 1;
+    load_64k(planes + (size_t)NX * BUF, lds0 + (uint32_t)(NX & 1) * BUF, wave, lane);
+  }
+  if (SKEL) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r) lookup<PL, HALF>(vlo[r], vhi[r], addr[r], mask[r]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int R, bool DESC, int SKEL>
+__device__ __forceinline__ void plane_sweep(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                            uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
+                                            const uint64_t (&mask)[R]) {
+  plane_pass<R, 0, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 1, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 2, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 3, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 4, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 5, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 6, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+  plane_pass<R, 7, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+}
+
+template <int R, int SKEL>
+__global__ __launch_bounds__(THREADS) void k_planes(const uint16_t* __restrict__ ids, const uint8_t* __restrict__ planes,
+                                                    uint64_t* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSP uint8_t*)lds4;
+  constexpr int UNITS = R / 4;
+  const uint32_t tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63u;
+  const size_t batch = (size_t)THREADS * R;
+  bool descending = false;
+  load_64k(planes, lds0, wave, lane);
+  load_64k(planes + BUF, lds0 + BUF, wave, lane);
+  u32x2 nxt[UNITS];
+  size_t b0 = (size_t)blockIdx.x * batch;
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) {
+    const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
+    nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+  }
+  wg_barrier();
+  for (; b0 < n; b0 += (size_t)gridDim.x * batch) {
+    uint32_t addr[R];
+    uint64_t mask[R];
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      addr[4 * k] = (nxt[k].x & 0xFFFF) * 2;
+      addr[4 * k + 1] = (nxt[k].x >> 16) * 2;
+      addr[4 * k + 2] = (nxt[k].y & 0xFFFF) * 2;
+      addr[4 * k + 3] = (nxt[k].y >> 16) * 2;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) mask[r] = __builtin_amdgcn_ballot_w64(addr[r] < BUF);
+    const size_t nb0 = b0 + (size_t)gridDim.x * batch;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = nb0 / 4 + (size_t)k * THREADS + tid;
+      nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+    }
+    uint32_t vlo[R], vhi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
+    if (!descending)
+      plane_sweep<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+    else
+      plane_sweep<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+    descending = !descending;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
+      if (u * 4 < n) {
+        store_nt(out + u * 4, vlo[4 * k], vhi[4 * k], vlo[4 * k + 1], vhi[4 * k + 1]);
+        store_nt(out + u * 4 + 2, vlo[4 * k + 2], vhi[4 * k + 2], vlo[4 * k + 3], vhi[4 * k + 3]);
+      }
+    }
+  }
+}
+
+template <typename F>
+float time_it(F f, int iters = 10) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  f();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int i = 0; i < iters; ++i) f();
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters * 1000.f;
+}
+
+int main() {
+  const size_t n = 100000000;
+  const uint32_t D = 65536;
+  std::vector<uint16_t> h_ids(n);
+  uint64_t x = 88172645463325252ull;
+  for (size_t i = 0; i < n; ++i) {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    h_ids[i] = (uint16_t)(x >> 20);
+  }
+  std::vector<uint64_t> h_dict(D);
+  for (uint32_t i = 0; i < D; ++i) {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    h_dict[i] = x;
+  }
+  std::vector<uint16_t> h_planes((size_t)4 * D);
+  for (int p = 0; p < 4; ++p)
+    for (uint32_t e = 0; e < D; ++e) h_planes[(size_t)p * D + e] = (uint16_t)(h_dict[e] >> (16 * p));
+  uint16_t* ids;
+  uint64_t *dict, *out;
+  uint8_t* planes;
+  CHECK(hipMalloc(&ids, n * 2 + 64));
+  CHECK(hipMalloc(&dict, D * 8));
+  CHECK(hipMalloc(&planes, D * 8));
+  CHECK(hipMalloc(&out, n * 8));
+  CHECK(hipMemcpy(ids, h_ids.data(), n * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dict, h_dict.data(), D * 8, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(planes, h_planes.data(), D * 8, hipMemcpyHostToDevice));
+  std::vector<uint64_t> h_out(1 << 16);
+  auto check = [&](const char* name) {
+    for (size_t at : {(size_t)0, n / 2, n - h_out.size()}) {
+      CHECK(hipMemcpy(h_out.data(), out + at, h_out.size() * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < h_out.size(); ++i)
+        if (h_out[i] != h_dict[h_ids[at + i]]) {
+          printf("  %s MISMATCH at %zu: %016llx vs %016llx\n", name, at + i, (unsigned long long)h_out[i],
+                 (unsigned long long)h_dict[h_ids[at + i]]);
+          return;
+        }
+    }
+    CHECK(hipMemset(out, 0, n * 8));
+  };
+  const double bytes = (double)n * 10;
+  auto report = [&](const char* name, float us) {
+    printf("  %-52s %8.1f us  %7.1f GB/s  %5.1f %% of 8 TB/s\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+    fflush(stdout);
+  };
+  float us;
+#define RUN_SLICES(R, SKEL)                                                                                                  \
+  {                                                                                                                          \
+    CHECK(hipFuncSetAttribute((const void*)k_slices<R, SKEL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));         \
+    us = time_it([&] { hipLaunchKernelGGL((k_slices<R, SKEL>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, dict, out, n); }); \
+    if (!SKEL) check("slices");                                                                                              \
+    char nm[96];                                                                                                             \
+    snprintf(nm, sizeof nm, "A slices  R=%d%s", R, SKEL ? "  (no lookups: DMA + ids + stores)" : "");                         \
+    report(nm, us);                                                                                                          \
+  }
+#define RUN_PLANES(R, SKEL)                                                                                                    \
+  {                                                                                                                            \
+    CHECK(hipFuncSetAttribute((const void*)k_planes<R, SKEL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));           \
+    us = time_it([&] { hipLaunchKernelGGL((k_planes<R, SKEL>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, planes, out, n); }); \
+    if (!SKEL) check("planes");                                                                                                \
+    char nm[96];                                                                                                               \
+    snprintf(nm, sizeof nm, "B planes  R=%d%s", R, SKEL ? "  (no lookups: DMA + ids + stores)" : "");                           \
+    report(nm, us);                                                                                                            \
+  }
+  RUN_SLICES(20, 0);
+  RUN_SLICES(20, 1);
+  RUN_PLANES(20, 0);
+  RUN_PLANES(20, 1);
+  RUN_SLICES(24, 0);
+  RUN_PLANES(24, 0);
+  RUN_PLANES(28, 0);
+  RUN_PLANES(32, 0);
+  RUN_PLANES(32, 1);
+  RUN_PLANES(16, 0);
+  return 0;
+}
