@@ -15,7 +15,11 @@
 //   - the dictionary streams through LDS in 64 KiB slices, double-buffered, by LDS-DMA
 //     (global_load_lds_dwordx4) issued by all 16 waves;
 //   - each pass looks up the ids that fall into the resident slice (their values go to registers
-//     of their own; an id is found by exactly one pass);
+//     of their own; an id is found by exactly one pass).  4-byte dictionaries are swept as they
+//     are; 8-byte dictionaries are swept as two dword PLANES (a copy made once per call by
+//     k_dict_planes: all low dwords, then all high dwords), a quarter of a plane (16384 entries,
+//     64 KiB) per pass, so that an id's LDS address is the same in every pass and a lookup is one
+//     byte-selecting compare that puts the quarter's lanes into EXEC plus one 4-byte LDS read;
 //   - while one page is being gathered, the next page's plan, segments and packed dwords are
 //     already being fetched (behind passes 0 and 1), so no memory round trip is exposed between
 //     pages;
@@ -121,7 +125,9 @@ __device__ __forceinline__ void load_slice(const uint8_t* slice_src, uint32_t by
 #pragma unroll
   for (int i = 0; i < (int)(DS_SLICE_BYTES / 16 / DS_THREADS); ++i) {
     const uint32_t piece0 = ((uint32_t)i * DS_WAVES + wave) * 64;  // wave-uniform
-    if (piece0 + lane < pieces) dma16(slice_src, (piece0 + lane) * 16, uni(lds_buf + piece0 * 16));
+    // (the lane offset is the same register for every piece: per-piece offsets would be hoisted out
+    // of the chunk loop and held in registers the kernel does not have)
+    if (piece0 < pieces && lane < pieces - piece0) dma16(slice_src + (size_t)piece0 * 16, lane * 16, uni(lds_buf + piece0 * 16));
   }
 }
 
@@ -346,10 +352,139 @@ __device__ __forceinline__ void extract(const PQD_LDS RleSeg* cs, const PageHead
   }
 }
 
+// One lookup in a quarter of a dictionary plane (8-byte dictionaries swept as dword planes, see
+// pqd_rle_plan.hpp): the lanes whose id lies in the quarter being swept read 4 bytes at LDS address
+// `addr` into `dst`, the others keep what they have.  The quarter of every id (bits 15..14) is kept
+// as one byte, four values to a register (`tags`); a byte-selecting compare against the pass's
+// quarter puts the matching lanes into EXEC, so a lookup is one vector instruction, one LDS read and
+// one scalar move, with no branch and no wait.  `all` = the lanes active around the call.
+template <int J>
+__device__ __forceinline__ void plane_lookup(uint32_t& dst, uint32_t addr, uint32_t tags, uint32_t quarter, uint64_t all) {
+#define PQD_PLANE_LOOKUP(SEL)                                                                              \
+  asm volatile("v_cmpx_eq_u32_sdwa vcc, %2, %3 src0_sel:" SEL " src1_sel:DWORD\n\tds_read_b32 %0, %1\n\ts_mov_b64 exec, %4" \
+               : "+v"(dst)                                                                                 \
+               : "v"(addr), "v"(tags), "s"(quarter), "s"(all)                                              \
+               : "vcc")
+  if (J == 0) PQD_PLANE_LOOKUP("BYTE_0");
+  if (J == 1) PQD_PLANE_LOOKUP("BYTE_1");
+  if (J == 2) PQD_PLANE_LOOKUP("BYTE_2");
+  if (J == 3) PQD_PLANE_LOOKUP("BYTE_3");
+#undef PQD_PLANE_LOOKUP
+}
+
+// `between(k)` is called in front of the lookups of unit row k (a hook for work to interleave).
+template <int R, typename Between>
+__device__ __forceinline__ void plane_lookups(uint32_t (&dst)[R], const uint32_t (&addr)[R], const uint32_t (&tags)[R / 4],
+                                              uint32_t quarter, uint64_t all, Between between) {
+  const uint32_t q = uni(quarter);  // wave-uniform by construction; made so for the compiler
+#pragma unroll
+  for (int k = 0; k < R / 4; ++k) {
+    between(k);
+    plane_lookup<0>(dst[4 * k], addr[4 * k], tags[k], q, all);
+    plane_lookup<1>(dst[4 * k + 1], addr[4 * k + 1], tags[k], q, all);
+    plane_lookup<2>(dst[4 * k + 2], addr[4 * k + 2], tags[k], q, all);
+    plane_lookup<3>(dst[4 * k + 3], addr[4 * k + 3], tags[k], q, all);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are invisible to the compiler
+}
+
+// Lookups of a chunk in an 8-byte dictionary (id[r] = the ids, below the dictionary's length).
+template <int R, int UNITS>
+__device__ __forceinline__ void sweep_8_byte_dictionary(uint32_t (&id)[R], uint32_t (&vlo)[R], uint32_t (&vhi)[R],
+                                                        uint32_t dict_len, uint32_t slot1,
+                                                        const uint8_t* plane_area, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                                        uint32_t& tag_s0, uint32_t& tag_s1, bool& descending PROF_FN_PARAM) {
+  {
+    // Plane sweep: pass s = plane * 4 + quarter brings 64 KiB (16384 entries x 4 bytes) of the low-
+    // or high-dword plane into LDS buffer (quarter & 1), so an id's LDS address is (4 * id) & 0x1FFFF
+    // in every pass.  Pass order alternates between chunks, as for slices: the two passes a chunk
+    // ends with are the two the next one starts with.  A dictionary of one quarter per plane (at most
+    // 16384 entries) keeps its low dwords in buffer 0 and its high dwords in buffer 1, both resident
+    // from chunk to chunk; the addresses then carry the buffer bit while the high plane is read.
+    const uint32_t entries = dict_len < 65536u ? dict_len : 65536u;
+    const uint32_t nq = (entries + DP_QUARTER_ENTRIES - 1) / DP_QUARTER_ENTRIES;  // quarters per plane: 1..4
+    const uint32_t NP = 2 * nq;
+    const uint8_t* slot_base = plane_area + (size_t)(slot1 - 1u) * DP_SLOT_BYTES;
+    uint32_t tags[R / 4];  // byte j of tags[k]: the quarter of value 4 * k + j
+#pragma unroll
+    for (int k = 0; k < R / 4; ++k) {
+      tags[k] = (id[4 * k] >> 14) | ((id[4 * k + 1] >> 14) << 8) | ((id[4 * k + 2] >> 14) << 16) | ((id[4 * k + 3] >> 14) << 24);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) id[4 * k + j] = (id[4 * k + j] << 2) & 0x1FFFFu;
+    }
+    const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+    auto pass_of = [&](uint32_t i) {  // sweep position -> plane * 4 + quarter
+      const uint32_t idx = descending ? NP - 1 - i : i;
+      const uint32_t pl = idx >= nq ? 1u : 0u;
+      return pl * 4u + (idx - pl * nq);
+    };
+    auto load_quarter = [&](uint32_t ps) {
+      const uint32_t qt = ps & 3u;
+      const uint32_t n_here = entries - qt * DP_QUARTER_ENTRIES < DP_QUARTER_ENTRIES ? entries - qt * DP_QUARTER_ENTRIES : DP_QUARTER_ENTRIES;
+      load_slice(slot_base + (size_t)(ps >> 2) * DP_PLANE_BYTES + (size_t)qt * DS_SLICE_BYTES, n_here * 4u,
+                 lds0 + (nq == 1 ? ps >> 2 : qt & 1u) * DS_SLICE_BYTES, wave, lane);
+    };
+    bool prefetch_only = true;
+    bool high_addresses = false;
+    for (uint32_t i = 0; i < NP; ++i) {
+      const uint32_t ps = pass_of(i);
+      const uint32_t curb = nq == 1 ? ps >> 2 : ps & 1u;
+      if ((nq == 1 && (ps >> 2) != 0) != high_addresses) {
+        high_addresses = !high_addresses;
+#pragma unroll
+        for (int r = 0; r < R; ++r) id[r] ^= DS_SLICE_BYTES;
+      }
+      // tags of plane passes are kept apart from slice numbers by bit 8
+      if ((curb ? tag_s1 : tag_s0) != (ps | 0x100u)) {
+        wg_barrier();  // nobody still reads this buffer
+        load_quarter(ps);
+        if (curb)
+          tag_s1 = ps | 0x100u;
+        else
+          tag_s0 = ps | 0x100u;
+        prefetch_only = false;
+      }
+      PROF(5)
+      if (prefetch_only)
+        wg_barrier_keep<UNITS>();  // the prefetch loads stay in flight
+      else
+        wg_barrier();
+      prefetch_only = false;
+      PROF(3)
+      // the next pass's quarter, if it goes to the other buffer, is requested in front of the lookups
+      uint32_t nx = 0;
+      bool bring_next = false;
+      if (i + 1 < NP) {
+        nx = pass_of(i + 1);
+        if ((nq == 1 ? nx >> 2 : nx & 1u) != curb && (curb ? tag_s0 : tag_s1) != (nx | 0x100u)) {
+          bring_next = true;
+          if (curb)
+            tag_s0 = nx | 0x100u;
+          else
+            tag_s1 = nx | 0x100u;
+        }
+      }
+      // (issuing the transfer piece by piece between the lookups (`between`),
+      // or behind them, were measured: 396 and 348 against 332-343 us per 100 M values: the waves queue
+      // for the memory pipeline either way, and LDS reads run slower beside an LDS-DMA burst wherever it is put)
+      if (bring_next) load_quarter(nx);
+      auto between = [&](int) {};
+      PROF(9)
+      if (ps < 4u)
+        plane_lookups(vlo, id, tags, ps & 3u, all, between);
+      else
+        plane_lookups(vhi, id, tags, ps & 3u, all, between);
+      PROF(4)
+    }
+    descending = !descending;
+  }
+}
+
 template <int ELEM>
 __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_result* __restrict__ results,
                                                                   const RleSeg* __restrict__ pool, uint32_t pool_chunks,
-                                                                  const uint32_t* __restrict__ cursor, uint32_t n_pages PROF_PARAM) {
+                                                                  const uint32_t* __restrict__ cursor, uint32_t n_pages,
+                                                                  const uint8_t* __restrict__ plane_area PROF_PARAM) {
   extern __shared__ u32x4 lds4[];
   uint8_t* lds = reinterpret_cast<uint8_t*>(lds4);
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
@@ -363,6 +498,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
   // which slice each LDS buffer holds (uniform over the workgroup)
   uint64_t tag_dict = 0;
+  uint32_t tag_len = 0;
   uint32_t tag_s0 = ~0u, tag_s1 = ~0u;
   uint32_t last_buf = 1;   // buffer of the latest pass
   uint32_t res_win = ~0u;  // window mode: which window (0 / 1) the two buffers hold; ~0: none
@@ -420,8 +556,11 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     const bool has_next = next_chunk < n_chunks;
     const uint32_t P = (dict_len + S - 1) / S;
     const uint8_t* dict_bytes = reinterpret_cast<const uint8_t*>(dict_addr);
-    if (dict_addr != tag_dict) {  // another dictionary: nothing resident is of use
+    // 8-byte dictionaries are looked up in dword planes: the slot of this one's plane copy
+    const uint32_t slot1 = ELEM == 8 ? uni(hd->nseg) >> 16 : 0u;
+    if (dict_addr != tag_dict || dict_len != tag_len) {  // another dictionary: nothing resident is of use
       tag_dict = dict_addr;
+      tag_len = dict_len;
       tag_s0 = tag_s1 = ~0u;
       res_win = ~0u;
     }
@@ -455,8 +594,10 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 
     // ---- 3. gather.  Byte offsets into the dictionary, so that a pass costs a subtraction and a
     // compare per id; a pass looks up the ids that fall into the part of the dictionary in LDS.
+    if constexpr (ELEM == 4) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) id[r] *= ELEM;
+      for (int r = 0; r < R; ++r) id[r] *= ELEM;
+    }
     uint32_t vlo[R], vhi[ELEM == 8 ? R : 1];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -537,6 +678,11 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     } else if (wide) {
       if (P > 0) lookups(0u, dict_bytes_total, 0u);  // the whole dictionary is in LDS
       PROF(4)
+    } else if constexpr (ELEM == 8) {
+      res_win = ~0u;
+      if (P > 0 && slot1 != 0)
+        sweep_8_byte_dictionary<R, UNITS>(id, vlo, vhi, dict_len, slot1, plane_area, lds0, wave, lane,
+                                          tag_s0, tag_s1, descending PROF_FN_ARG);
     } else {
       // More than four slices: one slice per pass, double-buffered.  Pass order alternates between
       // pages (0,1,..,P-1 then P-1,..,1,0): the two slices a page ends with are the two the next
@@ -622,7 +768,7 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
     // ---- 6. chunk end.  All atomicMin on this chunk's oob slot are in after the barrier; the slot
     // is next used three chunks on.  A chunk without a sweep has had no barrier that made sure the
     // chunk DMA issued above has landed: it takes the full one.
-    if (P == 0)
+    if (P == 0 || (ELEM == 8 && slot1 == 0))
       wg_barrier();
     else if (wide && !two_windows)
       wg_barrier_keep<UNITS>();  // the only barrier of such a chunk: waits for everything but its last stores
@@ -676,7 +822,7 @@ static void prof_report(uint32_t grid, hipStream_t stream) {
 #endif
 
 hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
-                                    uint32_t n_pages, int elem, hipStream_t stream) {
+                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -701,9 +847,9 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
   if (!g_prof && (e = hipMalloc((void**)&g_prof, 1024 * 24 * 8)) != hipSuccess) return e;
 #endif
   if (elem == 4)
-    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area PROF_ARG);
   else
-    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area PROF_ARG);
 #ifdef PQD_PROF
   prof_report(grid, stream);
 #endif

@@ -487,6 +487,49 @@ __device__ __forceinline__ void varint_of_dword(uint32_t x, uint32_t& header, ui
   }
 }
 
+// Key and first probe position of a dictionary in the plane-slot table (pqd_rle_plan.hpp).  Ids of
+// planned pages are below 65536 whatever the dictionary's length: entries beyond that are never read.
+__device__ __forceinline__ uint64_t dict_plane_key(const void* dict, uint32_t dict_len) {
+  const uint32_t entries = dict_len < 65536u ? dict_len : 65536u;
+  return ((uint64_t)(uintptr_t)dict & 0xFFFFFFFFFFFFull) | ((uint64_t)(entries - 1u) << 48);
+}
+__device__ __forceinline__ uint32_t dict_plane_hash(uint64_t key, uint32_t n_slots) {
+  return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) % n_slots;
+}
+
+// Claims a plane slot for every 8-byte dictionary of the batch: one lane per page; a page whose
+// dictionary is that of the page before it has nothing to do, so a column chunk's pages cost one
+// table access (the plan kernel then only reads the table: thousands of pages asking for the same
+// entry with atomics took longer than planning them).  Whoever puts a key into the table also lists
+// the slot for the kernel that fills it.
+__global__ __launch_bounds__(256) void k_dict_slots(const pqd_page_desc* __restrict__ descs, uint32_t n_pages,
+                                                    uint32_t* __restrict__ cursor, DictPlanes planes) {
+  const uint32_t page = blockIdx.x * 256u + threadIdx.x;
+  if (page >= n_pages || planes.n_slots == 0) return;
+  const pqd_page_desc d = descs[page];
+  if (d.encoding != PQD_ENC_RLE_DICTIONARY || d.elem_size != 8 || d.dict_len == 0 || ((uintptr_t)d.dict & 15u) != 0) return;
+  if (page > 0) {
+    const pqd_page_desc b = descs[page - 1];
+    if (b.dict == d.dict && b.dict_len == d.dict_len && b.encoding == d.encoding && b.elem_size == d.elem_size) return;
+  }
+  const uint64_t key = dict_plane_key(d.dict, d.dict_len);
+  uint32_t h = dict_plane_hash(key, planes.n_slots);
+  const uint32_t probes = planes.n_slots < DP_MAX_PROBES ? planes.n_slots : DP_MAX_PROBES;
+  for (uint32_t i = 0; i < probes; ++i) {
+    unsigned long long* e = reinterpret_cast<unsigned long long*>(planes.keys + h);
+    unsigned long long cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) {
+      cur = atomicCAS(e, 0ull, (unsigned long long)key);
+      if (cur == 0ull) {
+        planes.list[atomicAdd(cursor + 2, 1u)] = h;
+        return;
+      }
+    }
+    if (cur == key) return;
+    h = h + 1u == planes.n_slots ? 0u : h + 1u;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The plan kernel: one wave per page, pages of any length.  The plan is a list of chunks taken from
 // a shared pool (pqd_rle_plan.hpp): plain hybrid pages (want_dict == 0: levels, booleans, ids as
@@ -497,7 +540,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                                                                   pqd_page_result* __restrict__ results,
                                                                   RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
-                                                                  uint32_t n_pages, int want_dict, int elem) {
+                                                                  uint32_t n_pages, int want_dict, int elem,
+                                                                  DictPlanes planes) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
@@ -578,6 +622,24 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                            (passes <= 1 || (passes <= DS_MAX_PASSES && (uint64_t)d.dict_len * (uint32_t)elem <= 32ull * held));
     not_planned = not_planned || w > 16 || !sweepable;
   }
+  // 8-byte dictionaries are looked up in plane copies (pqd_rle_plan.hpp): the slot of this page's
+  // dictionary, claimed by k_dict_slots before this kernel ran.  No slot (table or area full): the
+  // page is left to the generic kernel, which reads the dictionary from memory.
+  uint32_t slot1 = 0;  // 1 + slot
+  const bool needs_planes = want_dict && elem == 8 && d.dict_len != 0 && !not_planned;
+  if (needs_planes && planes.n_slots != 0) {
+    const uint64_t key = dict_plane_key(d.dict, d.dict_len);
+    uint32_t h = dict_plane_hash(key, planes.n_slots);
+    const uint32_t probes = planes.n_slots < DP_MAX_PROBES ? planes.n_slots : DP_MAX_PROBES;
+    for (uint32_t i = 0; i < probes && slot1 == 0; ++i) {
+      const uint64_t cur = planes.keys[h];
+      if (cur == key) slot1 = h + 1u;
+      if (cur == 0ull) break;  // a free entry ends the probe sequence: the dictionary has no slot
+      h = h + 1u == planes.n_slots ? 0u : h + 1u;
+    }
+    slot1 = __builtin_amdgcn_readfirstlane(slot1);
+  }
+  not_planned = not_planned || (needs_planes && slot1 == 0);
   if (not_planned) {
     if (tid == 0) {
       plans[page].flags = PLAN_F_FALLBACK;
@@ -586,6 +648,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     }
     return;
   }
+  const uint32_t nseg_tag = slot1 << 16;
   if (tid == 0) {
     st.pos = pos;
     st.vals = 0;
@@ -701,7 +764,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.out = (uint64_t)(uintptr_t)d.out;
               hd.v0 = a;
               hd.v1 = b;
-              hd.nseg = k;
+              hd.nseg = k | nseg_tag;
               hd.w = w;
               hd.data_len = d.data_len;
               hd.stream_end = end;
@@ -843,7 +906,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         hd->out = (uint64_t)(uintptr_t)d.out;
         hd->v0 = v0;
         hd->v1 = v1;
-        hd->nseg = k;
+        hd->nseg = k | nseg_tag;
         hd->w = w;
         hd->data_len = d.data_len;
         hd->stream_end = end;
@@ -915,11 +978,13 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
 
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
-                                  hipStream_t stream) {
+                                  const DictPlanes& planes, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
+  if (want_dict && elem == 8 && planes.n_slots != 0)
+    hipLaunchKernelGGL(k_dict_slots, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, descs, n_pages, cursor, planes);
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
                      reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
-                     want_dict ? 1 : 0, elem);
+                     want_dict ? 1 : 0, elem, planes);
   return hipGetLastError();
 }
 

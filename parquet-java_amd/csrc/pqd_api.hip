@@ -23,8 +23,10 @@ constexpr uint32_t NOALLOC_MAX_PAGES = 2048;
 constexpr uint32_t NOALLOC_POOL_CHUNKS = 8192;  // chunk p for page p, the rest shared
 constexpr size_t NOALLOC_POOL_BYTES = (size_t)NOALLOC_POOL_CHUNKS * pqd::SEG_CHUNK * sizeof(pqd::RleSeg);
 constexpr size_t NOALLOC_PLANS_BYTES = (size_t)NOALLOC_MAX_PAGES * sizeof(pqd::RlePagePlan);
-constexpr size_t NOALLOC_COUNTER_BYTES = 256;
-constexpr size_t NOALLOC_BYTES = NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES + NOALLOC_COUNTER_BYTES;
+constexpr size_t NOALLOC_COUNTER_BYTES = 256 + (size_t)pqd::DP_MAX_SLOTS * 12;  // counters, plane key table, plane slot list
+constexpr uint32_t NOALLOC_PLANE_SLOTS = 8;  // plane copies of 8-byte dictionaries swept through LDS
+constexpr size_t NOALLOC_PLANE_BYTES = (size_t)NOALLOC_PLANE_SLOTS * pqd::DP_SLOT_BYTES;
+constexpr size_t NOALLOC_BYTES = NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES + NOALLOC_COUNTER_BYTES + NOALLOC_PLANE_BYTES;
 static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 
 namespace {
@@ -105,8 +107,24 @@ struct PlanScratch {
   uint32_t cap_pages = 0;
   void* gen_pool = nullptr;    // chunk pool: chunk p for page p, the rest handed out through counters[0]
   uint32_t gen_chunks = 0;
-  uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool
+  uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool, [1] pages left
+                                 // to the generic kernel, [2] plane slots claimed; behind the counter block:
+                                 // the key table and the list of the dictionary plane slots (pqd_rle_plan.hpp)
+  void* plane_area = nullptr;    // plane copies of 8-byte dictionaries, plane_slots x DP_SLOT_BYTES
+  uint32_t plane_slots = 0;
 };
+constexpr size_t COUNTER_BYTES = 256;
+constexpr size_t PLANE_KEYS_BYTES = (size_t)pqd::DP_MAX_SLOTS * 8, PLANE_LIST_BYTES = (size_t)pqd::DP_MAX_SLOTS * 4;
+constexpr size_t COUNTER_BLOCK_BYTES = COUNTER_BYTES + PLANE_KEYS_BYTES + PLANE_LIST_BYTES;
+
+pqd::DictPlanes planes_of(uint32_t* counters, void* area, uint32_t slots) {
+  pqd::DictPlanes dp;
+  dp.keys = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(counters) + COUNTER_BYTES);
+  dp.list = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(counters) + COUNTER_BYTES + PLANE_KEYS_BYTES);
+  dp.area = static_cast<uint8_t*>(area);
+  dp.n_slots = slots;
+  return dp;
+}
 std::mutex g_plan_mutex;  // guards the map itself (nodes of a std::map do not move)
 std::map<std::pair<int, void*>, PlanScratch> g_plan_scratch;
 
@@ -118,7 +136,7 @@ struct PlanLease {
 // Plans for n_pages pages and a chunk pool of two chunks per page plus a shared reserve (a
 // 20000-value level page needs 1-6 chunks, a 1 M-value page about 31; a page that finds the pool
 // empty is decoded by the generic kernel).  Returns with the scratch locked.
-int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, PlanLease* lease) {
+int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_plane_slots, PlanLease* lease) {
   int dev = 0;
   PQD_HIP(hipGetDevice(&dev));
   PlanScratch* ps;
@@ -128,7 +146,8 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, PlanLease* lease)
   }
   std::unique_lock<std::mutex> lock(ps->mu);
   const uint64_t want = (uint64_t)n_pages * 2 + 16384;
-  if (ps->cap_pages < n_pages || ps->gen_chunks < want || !ps->counters) {
+  if (want_plane_slots > pqd::DP_MAX_SLOTS) want_plane_slots = pqd::DP_MAX_SLOTS;
+  if (ps->cap_pages < n_pages || ps->gen_chunks < want || !ps->counters || ps->plane_slots < want_plane_slots) {
     // wait for work that may still use the old buffers, then replace them
     PQD_HIP(hipStreamSynchronize(stream));
     if (ps->cap_pages < n_pages) {
@@ -147,7 +166,14 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, PlanLease* lease)
       PQD_HIP(hipMalloc(&ps->gen_pool, (size_t)chunks * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
       ps->gen_chunks = (uint32_t)(chunks > 0xFFFFFFFFull ? 0xFFFFFFFFull : chunks);
     }
-    if (!ps->counters) PQD_HIP(hipMalloc((void**)&ps->counters, 256));
+    if (!ps->counters) PQD_HIP(hipMalloc((void**)&ps->counters, COUNTER_BLOCK_BYTES));
+    if (ps->plane_slots < want_plane_slots) {
+      if (ps->plane_area) (void)hipFree(ps->plane_area);
+      ps->plane_area = nullptr;
+      ps->plane_slots = 0;
+      PQD_HIP(hipMalloc(&ps->plane_area, (size_t)want_plane_slots * pqd::DP_SLOT_BYTES));
+      ps->plane_slots = want_plane_slots;
+    }
   }
   lease->ps = ps;
   lease->lock = std::move(lock);
@@ -164,6 +190,7 @@ void plan_scratch_drop(void* stream) {
         if (it->second.plans) (void)hipFree(it->second.plans);
         if (it->second.gen_pool) (void)hipFree(it->second.gen_pool);
         if (it->second.counters) (void)hipFree(it->second.counters);
+        if (it->second.plane_area) (void)hipFree(it->second.plane_area);
       }
       it = g_plan_scratch.erase(it);
     } else {
@@ -275,6 +302,22 @@ uint32_t usable_pool_chunks(uint32_t have) {
   if (!v) return have;
   const long lim = atol(v);
   return lim < 0 ? 0u : ((unsigned long)lim < have ? (uint32_t)lim : have);
+}
+
+// Plane slots a dictionary call of n_pages pages asks for, and how many of those the kernels may use
+// (PQD_PLANE_SLOTS lowers or raises it; 0 = none: the tests reach the gather-from-memory path with it).
+uint32_t wanted_plane_slots(uint32_t n_pages) {
+  uint32_t n = n_pages / 16;
+  n = n < 4 ? 4 : n;
+  if (const char* v = getenv("PQD_PLANE_SLOTS")) {
+    const long lim = atol(v);
+    n = lim < 0 ? 0u : (uint32_t)lim;
+  }
+  return n > pqd::DP_MAX_SLOTS ? pqd::DP_MAX_SLOTS : n;
+}
+uint32_t usable_plane_slots(uint32_t have, uint32_t n_pages) {
+  const uint32_t want = wanted_plane_slots(n_pages);
+  return want < have ? want : have;
 }
 
 // The same switch for plain hybrid pages: PQD_RLE_PATH=generic selects the single generic kernel.
@@ -523,12 +566,13 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         // 2. expansion of all chunks (workgroups take chunks from a counter)
         // 3. generic kernel for the pages the plan left over
         PlanLease lease;  // holds the scratch until the last launch below is enqueued
-        int st = plan_scratch_acquire(s, n_pages, &lease);
+        int st = plan_scratch_acquire(s, n_pages, 0, &lease);
         if (st) return st;
         PlanScratch& ps = *lease.ps;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
-        PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4, s));
+        PQD_HIP(hipMemsetAsync(ps.counters, 0, COUNTER_BYTES, s));
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4,
+                                            pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, s));
         PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, ps.counters, n_pages, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, ps.counters + 1, s));
       }
@@ -542,16 +586,21 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         // 2. expansion + sliced LDS gather, chunk by chunk
         // 3. generic kernel for the pages the plan left over
         PlanLease lease;  // holds the scratch until the last launch below is enqueued
-        int st = plan_scratch_acquire(s, n_pages, &lease);
+        // 8-byte dictionaries beyond one LDS slice are swept as dword planes: room for the plane copies
+        // of one dictionary per 16 pages (at least 4, at most DP_MAX_SLOTS; PQD_PLANE_SLOTS overrides);
+        // dictionaries that find no slot are gathered from memory
+        int st = plan_scratch_acquire(s, n_pages, elem_size == 8 ? wanted_plane_slots(n_pages) : 0u, &lease);
         if (st) return st;
         PlanScratch& ps = *lease.ps;
-        PQD_HIP(hipMemsetAsync(ps.counters, 0, 256, s));
+        const pqd::DictPlanes planes = planes_of(ps.counters, ps.plane_area, elem_size == 8 ? usable_plane_slots(ps.plane_slots, n_pages) : 0u);
+        PQD_HIP(hipMemsetAsync(ps.counters, 0, planes.n_slots ? COUNTER_BYTES + PLANE_KEYS_BYTES : COUNTER_BYTES, s));
         if ((st = phase_mark(0, s))) return st;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, true,
-                                            elem_size, s));
+                                            elem_size, planes, s));
+        PQD_HIP(pqd::launch_dict_planes(planes, ps.counters, s));
         if ((st = phase_mark(1, s))) return st;
-        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, s));
+        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, planes.area, s));
         if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s));
         if ((st = phase_mark(3, s))) return st;
@@ -594,13 +643,16 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
   uint32_t* counters = reinterpret_cast<uint32_t*>(base + NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES);
   const uint32_t pool_chunks = usable_pool_chunks(NOALLOC_POOL_CHUNKS);
   const bool dict = encoding == PQD_ENC_RLE_DICTIONARY;
-  // the array keeps the last call's contents: the counters must start at zero; plans and chunks are
-  // written by the plan kernel before anything reads them
-  PQD_HIP(hipMemsetAsync(counters, 0, NOALLOC_COUNTER_BYTES, s));
-  PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, s));
-  if (dict)
-    PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, s));
-  else
+  const pqd::DictPlanes planes = planes_of(counters, base + NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES + NOALLOC_COUNTER_BYTES,
+                                           dict && elem_size == 8 ? usable_plane_slots(NOALLOC_PLANE_SLOTS, NOALLOC_PLANE_SLOTS * 16) : 0u);
+  // the array keeps the last call's contents: the counters and the plane key table must start at
+  // zero; plans, chunks and plane copies are written by the kernels before anything reads them
+  PQD_HIP(hipMemsetAsync(counters, 0, COUNTER_BYTES + PLANE_KEYS_BYTES, s));
+  PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, planes, s));
+  if (dict) {
+    PQD_HIP(pqd::launch_dict_planes(planes, counters, s));
+    PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, planes.area, s));
+  } else
     PQD_HIP(pqd::launch_rle_expand(pool, pool_chunks, counters, n_pages, s));
   PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s));
   return PQD_OK;

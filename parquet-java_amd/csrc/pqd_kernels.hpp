@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/pqd.h"
+#include "pqd_rle_plan.hpp"
 
 namespace pqd {
 
@@ -22,15 +23,18 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
 // segments in `pool` (pqd_rle_plan.hpp): `plans` holds n_pages RlePagePlan records, `pool` pool_chunks
 // chunks, `cursor` two zeroed counters (chunks taken from the pool's shared tail; pages left to the
 // generic kernel)
+// (dictionary pages of 8-byte values: `planes` is where dictionaries that need plane copies get their slot)
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
-                                  hipStream_t stream);
+                                  const DictPlanes& planes, hipStream_t stream);
+// fills the plane slots the plan kernel claimed (their number: cursor[2])
+hipError_t launch_dict_planes(const DictPlanes& planes, const uint32_t* cursor, hipStream_t stream);
 // plain hybrid pages: expansion of all chunks
 hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather
 hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
-                                    uint32_t n_pages, int elem, hipStream_t stream);
+                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream);
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream);
 hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,

@@ -46,7 +46,7 @@ struct RleChunkHead {
   uint64_t data;        // the page's stream
   uint64_t out;         // the page's output (element 0)
   uint32_t v0, v1;      // output values covered
-  uint32_t nseg;
+  uint32_t nseg;        // bits 0..15: segments; bits 16..31: 1 + the dictionary's plane slot (0: none), see DictPlanes
   uint32_t w;
   uint32_t data_len;
   uint32_t stream_end;  // bytes at or past it read as zero
@@ -67,6 +67,26 @@ constexpr uint32_t DS_SLICE_BYTES = 64 * 1024;
 constexpr uint32_t DS_TILE_VALUES = 1024 * 20;
 static_assert(DS_TILE_VALUES <= SEG_TABLE_BLOCKS * SEG_BLOCK, "the block table covers a whole tile");
 constexpr uint32_t DS_MAX_PASSES = 32;
+
+// Plane copies of 8-byte dictionaries that are swept through LDS (more than DS_SLICE_BYTES of entries,
+// at most 65536 of them).  The sliced gather looks such a dictionary up four bytes at a time: slot s of
+// the plane area holds the LOW dwords of all entries at byte 0 and the HIGH dwords at byte
+// DP_PLANE_BYTES, so that a quarter of a plane (DP_QUARTER_ENTRIES entries, 64 KiB) is one contiguous
+// piece for the LDS-DMA.  The plan kernel finds or claims the slot of a page's dictionary in a small
+// open-addressing table keyed by the dictionary's address and length (`keys`, zeroed per call), and
+// lists the slots it claimed (`list`, their number in counter 2 of the call's counter block);
+// k_dict_planes then fills them, and the chunk headers carry the slot to the gather.
+constexpr uint32_t DP_PLANE_BYTES = 256 * 1024;
+constexpr uint32_t DP_SLOT_BYTES = 2 * DP_PLANE_BYTES;
+constexpr uint32_t DP_QUARTER_ENTRIES = 16384;
+constexpr uint32_t DP_MAX_SLOTS = 512;
+constexpr uint32_t DP_MAX_PROBES = 32;
+struct DictPlanes {
+  uint64_t* keys;    // n_slots entries: 0 = free, else dictionary address | (entries - 1) << 48
+  uint32_t* list;    // slots claimed in this call
+  uint8_t* area;     // n_slots x DP_SLOT_BYTES
+  uint32_t n_slots;  // 0: no plane area (every 8-byte dictionary beyond one slice is gathered from memory)
+};
 
 // Per-page record of the plan kernel.  `flags` belongs to the page with that index; `fallback_page`
 // is a dense list: entry i names the i-th page left to the generic kernel (their number is counter 1

@@ -636,3 +636,31 @@ def test_dictionary_rle_value_wider_than_the_id_width(gpu, orc, elem, dict_path)
         assert st == ost and written == ovals.size and (out.view(dt)[:written] == ovals).all() and (guard == 0xA5).all()
         res.append((st, written))
     assert res == [(0, 20), (pq.DICT_OOB, 8)]
+
+
+@pytest.mark.parametrize("slots", [None, "1", "0"])
+def test_eight_byte_dictionaries_of_every_size_class(gpu, orc, monkeypatch, slots):
+    """8-byte dictionaries are looked up in dword planes, a quarter (16384 entries) of a plane at a time:
+    one quarter per plane (both resident), two, three and four quarters, the quarter boundaries, a
+    dictionary longer than 16-bit ids can reach; several dictionaries in one call, with room for all of
+    their plane copies, for one of them (the others go to the generic kernel) and for none."""
+    import parquet_java_amd as pq
+    if slots is not None:
+        monkeypatch.setenv("PQD_PLANE_SLOTS", slots)
+    rng = np.random.default_rng(99)
+    pages, expect = [], []
+    for n_dict in (1, 2, 5, 8191, 8192, 8193, 16383, 16384, 16385, 20000, 32767, 32768, 32769, 40000, 49152, 49153, 65535, 65536, 70000):
+        dic = rng.integers(-(1 << 63), (1 << 63) - 1, n_dict, dtype=np.int64)
+        reach = min(n_dict, 65536)
+        for n in (20000, 777):
+            ids = rng.integers(0, reach, n).astype(np.int32)
+            ids[:8] = [0, reach - 1, reach // 2, max(reach // 4 - 1, 0), reach // 4, max(3 * reach // 4 - 1, 0), 3 * reach // 4, reach - 1]
+            ids[8:16] = np.minimum([0, 16383, 16384, 32767, 32768, 49151, 49152, 65535], reach - 1)
+            if n == 777:
+                ids[400:] = ids[3]  # an RLE run
+            pages.append(gpu.Page(orc.dict_encode_ids(ids, n_dict), n, pq.ENC_RLE_DICTIONARY, 8, dictionary=dic))
+            expect.append(dic[ids])
+    for (st, written, _, out, guard), want in zip(gpu.decode_pages(pages), expect):
+        assert st == 0 and written == want.size
+        assert (out.view(np.int64) == want).all()
+        assert (guard == 0xA5).all()

@@ -63,149 +63,64 @@ __device__ __forceinline__ void store_nt(uint64_t* o, uint32_t a, uint32_t b, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// A. slices of whole entries
-template <int R, int SKEL>
-__global__ __launch_bounds__(THREADS) void k_slices(const uint16_t* __restrict__ ids, const uint64_t* __restrict__ dict,
-                                                    uint64_t* __restrict__ out, size_t n) {
-  extern __shared__ u32x4 lds4[];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSP uint8_t*)lds4;
-  constexpr int UNITS = R / 4;
-  constexpr uint32_t P = 8;
-  const uint32_t tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63u;
-  const size_t batch = (size_t)THREADS * R;
-  const uint8_t* dbytes = reinterpret_cast<const uint8_t*>(dict);
-  bool descending = false;
-  load_64k(dbytes, lds0, wave, lane);
-  load_64k(dbytes + BUF, lds0 + BUF, wave, lane);
-  u32x2 nxt[UNITS];
-  size_t b0 = (size_t)blockIdx.x * batch;
-#pragma unroll
-  for (int k = 0; k < UNITS; ++k) {
-    const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
-    nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
-  }
-  wg_barrier();
-  for (; b0 < n; b0 += (size_t)gridDim.x * batch) {
-    uint32_t id[R];
-#pragma unroll
-    for (int k = 0; k < UNITS; ++k) {
-      id[4 * k] = (nxt[k].x & 0xFFFF) * 8;
-      id[4 * k + 1] = (nxt[k].x >> 16) * 8;
-      id[4 * k + 2] = (nxt[k].y & 0xFFFF) * 8;
-      id[4 * k + 3] = (nxt[k].y >> 16) * 8;
-    }
-    const size_t nb0 = b0 + (size_t)gridDim.x * batch;
-#pragma unroll
-    for (int k = 0; k < UNITS; ++k) {
-      const size_t u = nb0 / 4 + (size_t)k * THREADS + tid;
-      nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
-    }
-    uint32_t vlo[R], vhi[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
-    // slice s lives in buffer s & 1; the two slices the last batch ended with are resident
-    for (uint32_t i = 0; i < P; ++i) {
-      const uint32_t s = descending ? P - 1 - i : i;
-      const uint32_t curb = s & 1u;
-      if (i >= 2) {  // slice s is not resident: it was requested two passes ago into this buffer's twin... see below
-      }
-      // wait for this pass's slice (requested one pass ago) and for everybody to be done with the other buffer
-      if (i == 0)
-        wg_barrier_keep<UNITS>();
-      else
-        wg_barrier();
-      // request the slice of the next pass into the other buffer (passes 0 and 1 find theirs resident)
-      if (i >= 1 && i + 1 < P) {
-        const uint32_t nx = descending ? s - 1 : s + 1;
-        load_64k(dbytes + (size_t)nx * BUF, lds0 + (nx & 1u) * BUF, wave, lane);
-      }
-      if (SKEL) continue;
-      const LDSP uint8_t* buf = (const LDSP uint8_t*)(uintptr_t)(lds0 + curb * BUF);
-      const uint32_t base = s * BUF;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t a = id[r] - base;
-        if (a < BUF) {
-          const u32x2 t = *(const LDSP u32x2*)(buf + a);
-          vlo[r] = t.x;
-          vhi[r] = t.y;
-        }
-      }
-    }
-    descending = !descending;
-#pragma unroll
-    for (int k = 0; k < UNITS; ++k) {
-      const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
-      if (u * 4 < n) {
-        store_nt(out + u * 4, vlo[4 * k], vhi[4 * k], vlo[4 * k + 1], vhi[4 * k + 1]);
-        store_nt(out + u * 4 + 2, vlo[4 * k + 2], vhi[4 * k + 2], vlo[4 * k + 3], vhi[4 * k + 3]);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// B. planes.  One lookup: 2 bytes of plane PL (0..3) of entry id into the matching half of vlo / vhi,
-// for the lanes in `mask` (HALF 0) or outside it (HALF 1).  EXEC is all ones on entry and on exit.
-template <int PL, int HALF>
-__device__ __forceinline__ void lookup(uint32_t& vlo, uint32_t& vhi, uint32_t addr, uint64_t mask) {
+// C. dword planes in quarters.  Plane 0 = the low dwords of all entries (256 KiB), plane 1 = the high
+// dwords.  A pass brings one quarter of a plane (16384 entries x 4 bytes = 64 KiB) into LDS buffer
+// (quarter & 1), so an entry's LDS address is always (4 * id) & 0x1FFFF.  Which quarter an id belongs to
+// is kept as two lane masks per value (bit 15 and bit 14 of the id), computed once per batch; a
+// lookup is one scalar instruction that puts the quarter's lanes into EXEC and one 4-byte LDS read
+// into the whole result register: no vector arithmetic, no branch, no merge.
+template <int PL, int QT>
+__device__ __forceinline__ void lookup(uint32_t& vlo, uint32_t& vhi, uint32_t addr, uint64_t hi, uint64_t lo) {
+#define PQD_LOOKUP(SETEXEC, DST)                                                                     \
+  asm volatile(SETEXEC "\n\tds_read_b32 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(DST) : "v"(addr), "s"(hi), "s"(lo) : "scc")
   if (PL == 0) {
-    if (HALF == 0)
-      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
-    else
-      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
-  } else if (PL == 1) {
-    if (HALF == 0)
-      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
-    else
-      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vlo) : "v"(addr), "s"(mask));
-  } else if (PL == 2) {
-    if (HALF == 0)
-      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
-    else
-      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+    if (QT == 0) PQD_LOOKUP("s_nor_b64 exec, %2, %3", vlo);
+    if (QT == 1) PQD_LOOKUP("s_andn2_b64 exec, %3, %2", vlo);
+    if (QT == 2) PQD_LOOKUP("s_andn2_b64 exec, %2, %3", vlo);
+    if (QT == 3) PQD_LOOKUP("s_and_b64 exec, %2, %3", vlo);
   } else {
-    if (HALF == 0)
-      asm volatile("s_mov_b64 exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
-    else
-      asm volatile("s_andn2_b64 exec, exec, %2\n\tds_read_u16_d16_hi %0, %1\n\ts_mov_b64 exec, -1" : "+v"(vhi) : "v"(addr), "s"(mask));
+    if (QT == 0) PQD_LOOKUP("s_nor_b64 exec, %2, %3", vhi);
+    if (QT == 1) PQD_LOOKUP("s_andn2_b64 exec, %3, %2", vhi);
+    if (QT == 2) PQD_LOOKUP("s_andn2_b64 exec, %2, %3", vhi);
+    if (QT == 3) PQD_LOOKUP("s_and_b64 exec, %2, %3", vhi);
   }
+#undef PQD_LOOKUP
 }
 
-// Pass Q of a sweep (Q = 0..7 in sweep order; DESC: the sweep runs from plane 3 down).  Plane-half
-// (p, h) always lives in buffer h, at LDS address h * 64 KiB, so an entry's address is 2 * id.
+// Pass Q of a sweep (Q = 0..7 in sweep order; DESC: the sweep runs from the last quarter down).
+// SKEL 1: no lookups; SKEL 2: no DMA after the first two quarters (timing only, wrong results).
 template <int R, int Q, bool DESC, int SKEL>
 __device__ __forceinline__ void plane_pass(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
                                            uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
-                                           const uint64_t (&mask)[R]) {
-  constexpr int S = DESC ? 7 - Q : Q;  // plane-half index: plane S >> 1, half S & 1
-  constexpr int PL = S >> 1, HALF = S & 1;
+                                           const uint64_t (&mhi)[R], const uint64_t (&mlo)[R]) {
+  constexpr int S = DESC ? 7 - Q : Q;  // plane S >> 2, quarter S & 3
+  constexpr int PL = S >> 2, QT = S & 3;
   if (Q == 0)
     wg_barrier_keep<R / 4>();  // the id prefetch stays in flight
   else
     wg_barrier();
-  if (Q >= 1 && Q + 1 < 8) {  // passes 0 and 1 find their plane-halves resident
+  if (Q >= 1 && Q + 1 < 8 && SKEL != 2) {  // passes 0 and 1 find their quarters resident
     constexpr int NX = DESC ? S - 1 : S + 1;
     load_64k(planes + (size_t)NX * BUF, lds0 + (uint32_t)(NX & 1) * BUF, wave, lane);
   }
-  if (SKEL) return;
+  if (SKEL == 1) return;
 #pragma unroll
-  for (int r = 0; r < R; ++r) lookup<PL, HALF>(vlo[r], vhi[r], addr[r], mask[r]);
+  for (int r = 0; r < R; ++r) lookup<PL, QT>(vlo[r], vhi[r], addr[r], mhi[r], mlo[r]);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 template <int R, bool DESC, int SKEL>
 __device__ __forceinline__ void plane_sweep(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
                                             uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
-                                            const uint64_t (&mask)[R]) {
-  plane_pass<R, 0, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 1, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 2, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 3, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 4, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 5, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 6, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
-  plane_pass<R, 7, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+                                            const uint64_t (&mhi)[R], const uint64_t (&mlo)[R]) {
+  plane_pass<R, 0, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 1, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 2, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 3, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 4, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 5, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 6, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass<R, 7, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
 }
 
 template <int R, int SKEL>
@@ -229,16 +144,20 @@ __global__ __launch_bounds__(THREADS) void k_planes(const uint16_t* __restrict__
   wg_barrier();
   for (; b0 < n; b0 += (size_t)gridDim.x * batch) {
     uint32_t addr[R];
-    uint64_t mask[R];
+    uint64_t mhi[R], mlo[R];
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
-      addr[4 * k] = (nxt[k].x & 0xFFFF) * 2;
-      addr[4 * k + 1] = (nxt[k].x >> 16) * 2;
-      addr[4 * k + 2] = (nxt[k].y & 0xFFFF) * 2;
-      addr[4 * k + 3] = (nxt[k].y >> 16) * 2;
+      addr[4 * k] = (nxt[k].x & 0xFFFF) * 4;
+      addr[4 * k + 1] = (nxt[k].x >> 16) * 4;
+      addr[4 * k + 2] = (nxt[k].y & 0xFFFF) * 4;
+      addr[4 * k + 3] = (nxt[k].y >> 16) * 4;
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) mask[r] = __builtin_amdgcn_ballot_w64(addr[r] < BUF);
+    for (int r = 0; r < R; ++r) {
+      mhi[r] = __builtin_amdgcn_ballot_w64((addr[r] & 0x20000u) != 0);
+      mlo[r] = __builtin_amdgcn_ballot_w64((addr[r] & 0x10000u) != 0);
+      addr[r] &= 0x1FFFFu;
+    }
     const size_t nb0 = b0 + (size_t)gridDim.x * batch;
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
@@ -249,9 +168,9 @@ __global__ __launch_bounds__(THREADS) void k_planes(const uint16_t* __restrict__
 #pragma unroll
     for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
     if (!descending)
-      plane_sweep<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+      plane_sweep<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
     else
-      plane_sweep<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mask);
+      plane_sweep<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
     descending = !descending;
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
@@ -298,9 +217,11 @@ int main() {
     x ^= x << 17;
     h_dict[i] = x;
   }
-  std::vector<uint16_t> h_planes((size_t)4 * D);
-  for (int p = 0; p < 4; ++p)
-    for (uint32_t e = 0; e < D; ++e) h_planes[(size_t)p * D + e] = (uint16_t)(h_dict[e] >> (16 * p));
+  std::vector<uint32_t> h_planes((size_t)2 * D);
+  for (uint32_t e = 0; e < D; ++e) {
+    h_planes[e] = (uint32_t)h_dict[e];
+    h_planes[(size_t)D + e] = (uint32_t)(h_dict[e] >> 32);
+  }
   uint16_t* ids;
   uint64_t *dict, *out;
   uint8_t* planes;
@@ -330,33 +251,20 @@ int main() {
     fflush(stdout);
   };
   float us;
-#define RUN_SLICES(R, SKEL)                                                                                                  \
-  {                                                                                                                          \
-    CHECK(hipFuncSetAttribute((const void*)k_slices<R, SKEL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));         \
-    us = time_it([&] { hipLaunchKernelGGL((k_slices<R, SKEL>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, dict, out, n); }); \
-    if (!SKEL) check("slices");                                                                                              \
-    char nm[96];                                                                                                             \
-    snprintf(nm, sizeof nm, "A slices  R=%d%s", R, SKEL ? "  (no lookups: DMA + ids + stores)" : "");                         \
-    report(nm, us);                                                                                                          \
-  }
 #define RUN_PLANES(R, SKEL)                                                                                                    \
   {                                                                                                                            \
     CHECK(hipFuncSetAttribute((const void*)k_planes<R, SKEL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));           \
     us = time_it([&] { hipLaunchKernelGGL((k_planes<R, SKEL>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, planes, out, n); }); \
-    if (!SKEL) check("planes");                                                                                                \
+    if (!SKEL) check("planes"); else CHECK(hipMemset(out, 0, n * 8));                                                                                                \
     char nm[96];                                                                                                               \
-    snprintf(nm, sizeof nm, "B planes  R=%d%s", R, SKEL ? "  (no lookups: DMA + ids + stores)" : "");                           \
+    snprintf(nm, sizeof nm, "dword planes in quarters  R=%d%s", R, SKEL == 1 ? "  (no lookups: DMA + ids + stores)" : SKEL == 2 ? "  (no DMA: ids + lookups + stores)" : "");                           \
     report(nm, us);                                                                                                            \
   }
-  RUN_SLICES(20, 0);
-  RUN_SLICES(20, 1);
   RUN_PLANES(20, 0);
   RUN_PLANES(20, 1);
-  RUN_SLICES(24, 0);
-  RUN_PLANES(24, 0);
-  RUN_PLANES(28, 0);
-  RUN_PLANES(32, 0);
-  RUN_PLANES(32, 1);
+  RUN_PLANES(20, 2);
   RUN_PLANES(16, 0);
+  RUN_PLANES(24, 0);
+  RUN_PLANES(20, 0);
   return 0;
 }
