@@ -139,6 +139,88 @@ def cpu_baseline(seconds, seed, threads=1):
                       f"{threads} thread(s), {dt:.1f} s"}
 
 
+def config1_sweep(device, stream, timed, n_pages=256, n_values=1_000_000):
+    """BASELINE.json configs[0] on the device: `n_pages` distinct pages of `n_values` INT32 values per bit
+    width 1..32, RLE / bit-packing hybrid as parquet-java writes non-repeating data (bit-packed runs of 63
+    groups = 504 values behind 1-byte headers, RunLengthBitPackingHybridEncoder.java:185-235), decoded by
+    one pqd_decode_pages_dev call per width.  Payload bytes are random, which makes the values random
+    w-bit numbers; two pages per width are re-derived from the payload bits with torch and compared."""
+    groups = n_values // 8
+    full, tail = divmod(groups, 63)
+    out = torch.empty((n_pages, n_values), dtype=torch.int32, device=device)
+    g = torch.Generator(device=device)
+    res = {}
+    for w in range(1, 33):
+        g.manual_seed(42 + w)
+        payload = torch.randint(0, 256, (n_pages, groups * w), dtype=torch.uint8, device=device, generator=g)
+        parts = []
+        if full:
+            body = payload[:, :full * 63 * w].reshape(n_pages, full, 63 * w)
+            head = torch.full((n_pages, full, 1), (63 << 1) | 1, dtype=torch.uint8, device=device)
+            parts.append(torch.cat([head, body], 2).reshape(n_pages, -1))
+        if tail:
+            parts.append(torch.full((n_pages, 1), (tail << 1) | 1, dtype=torch.uint8, device=device))
+            parts.append(payload[:, full * 63 * w:])
+        blob = torch.cat(parts, 1).contiguous()
+        page_len = blob.shape[1]
+        pages = [dict(data=blob.data_ptr() + i * page_len, out=out.data_ptr() + i * n_values * 4, data_len=page_len,
+                      num_values=n_values, encoding=pq.ENC_RLE, elem_size=4, bit_width=w) for i in range(n_pages)]
+        d_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(pages))).to(device)
+        d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
+        out.zero_()
+        ms = timed(lambda: pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n_pages, pq.ENC_RLE, 4, stream), iters=5)
+        status, written, _ = pq.results_from_numpy(d_res.cpu().numpy())
+        ok = bool((status == 0).all() and (written == n_values).all())
+        for i in (0, n_pages - 1):
+            bits = ((payload[i].to(torch.int64)[:, None] >> torch.arange(8, device=device)) & 1).reshape(-1, w)
+            vals = (bits << torch.arange(w, device=device)).sum(1).to(torch.int32)  # width 32 wraps to the bit pattern
+            ok = ok and bool(torch.equal(vals, out[i]))
+            del bits, vals
+        alg = n_pages * (page_len + n_values * 4)
+        res[str(w)] = {"ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
+                       "decoded_GBps": round(n_pages * n_values * 4 / ms / 1e6, 1), "verified": ok}
+        del payload, blob, parts, d_descs, d_res
+    del out
+    torch.cuda.empty_cache()
+    return {"pages": n_pages, "values_per_page": n_values, "by_bit_width": res,
+            "note": "algorithmic bytes = encoded page + 4 bytes per value; distinct pages (2.0 GiB decoded per call: beyond the 256 MiB Infinity Cache)"}
+
+
+def sources_digest():
+    """sha256 over the kernel sources (the same function as in tools/pmc_traffic.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "parquet-java_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: starts N fresh processes, one rank per GPU, with the
+    environment torch.distributed.run would give them, and returns the worst exit code.  The parent makes
+    no GPU call (counting devices does not initialise the runtime) and never execs; rank 0 prints the line.
+    PQD_BENCH_ONE_GPU=1 puts every rank on device 0 (a rehearsal of the N-rank path on a one-GPU box)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    one_gpu = bool(os.environ.get("PQD_BENCH_ONE_GPU"))
+    if have < n and not one_gpu:
+        print(f"bench.py: --gpus {n} but only {have} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if one_gpu else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,18 +229,27 @@ def main():
     ap.add_argument("--pages", type=int, default=5000, help="pages per column per GPU (5000 x 20000 = 100 M rows)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-config1", action="store_true", help="skip the 32-width sweep of 1 M-value hybrid pages in extras")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("PQD_BENCH_FORCE_DIST"):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     # (PQD_BENCH_FORCE_DIST=1 takes the process-group path with a single rank too: a rehearsal on a one-GPU box)
     distributed = world > 1 or bool(os.environ.get("PQD_BENCH_FORCE_DIST"))
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PQD_BENCH_ONE_GPU"):  # several ranks on one device: RCCL refuses that, gloo carries the barrier
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pq.init(local_rank)
@@ -216,7 +307,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("PQD_BENCH_ONE_GPU") else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -226,7 +317,7 @@ def main():
     # ---- outside the timed region: the other shapes of this workload, for the record
     extras = {}
     if rank == 0:
-        def timed(fn, iters=10):
+        def timed(fn, iters=10):  # noqa: E306
             fn()
             torch.cuda.synchronize()
             a, b = Event(), Event()
@@ -312,6 +403,11 @@ def main():
             "mean_value_bytes": round(total_bytes / (args.pages * PAGE_VALUES), 2), "verified_pages": chk, "verified": ok}
         pq.lib.pqd_dict_destroy(handle)
         del b_offsets, b_bytes, t_page
+        if not args.no_config1:
+            for c in cols:  # make room: the columns of the timed region are no longer needed
+                c["out"] = c["blob"] = c["ids"] = None
+            torch.cuda.empty_cache()
+            extras["config1_hybrid_int32_pages_1M_values"] = config1_sweep(device, stream, timed)
 
     n_vals = args.pages * PAGE_VALUES
     decoded_bytes_step = n_vals * (4 + 8)
@@ -324,11 +420,15 @@ def main():
     value = decoded_bytes_step * world / (elapsed / args.steps) / 1e9
 
     if rank == 0:
+        # HBM-side bytes per launch from the PMC passes (tools/pmc_traffic.sh): a number measured in
+        # another run, so it is reported only while the kernel sources are the ones it was measured on
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("k_dict_pages_sliced_8_bytes_per_launch")
+                rec = json.load(open(pmc))
+                if rec.get("sources_sha256") == sources_digest():
+                    traffic = rec.get("k_dict_pages_sliced_8_bytes_per_launch")
             except Exception:
                 traffic = None
         achieved = k64_alg_bytes / (k64_ms * 1e-3) / 1e9

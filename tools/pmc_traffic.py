@@ -1,22 +1,41 @@
 #!/usr/bin/env python3
-"""Reads the two rocprofv3 --pmc result databases (one pass FETCH_SIZE, one pass WRITE_SIZE; the TCC
-block cannot hold both) and writes profiles/pmc_traffic.json: HBM-side bytes per launch of the
-library's kernels.  FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte
-requests as 64 bytes, so it is doubled (exact for 16-byte-per-lane streaming reads; this library's
-reads are 12-byte-per-lane loads and 16-byte LDS-DMA, so read it as an estimate).
+"""Reads the counter CSVs of two rocprofv3 --pmc passes (one FETCH_SIZE, one WRITE_SIZE: the TCC block
+cannot hold both) and writes profiles/pmc_traffic.json: HBM-side bytes per launch of the library's
+kernels, with the digest of the kernel sources they were measured on (bench.py reports the traffic
+only while the sources still have that digest).  FETCH_SIZE and WRITE_SIZE are reported in KiB; on
+gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so it is doubled (exact for 16-byte-per-lane
+streaming reads; this library's reads are 12-byte-per-lane loads and 16-byte LDS-DMA, so read it as an
+estimate).
 
-    pmc_traffic.py fetch_results.db write_results.db out.json
+    pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv out.json
 """
+import collections
+import csv
+import hashlib
 import json
-import sqlite3
+import os
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def per_kernel(db_path, counter):
-    cur = sqlite3.connect(db_path).cursor()
-    rows = cur.execute("select name, count(*), avg(counter_value) from pmc_events where counter_name = ? "
-                       "and name like '%pqd::%' group by name", (counter,)).fetchall()
-    return {r[0]: (r[1], r[2]) for r in rows}
+
+def sources_digest():
+    """sha256 over the kernel sources (the same function as in bench.py)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "parquet-java_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "pqd::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
 
 def short(name):
@@ -24,12 +43,12 @@ def short(name):
     return n.replace("<", "_").replace(">", "").replace(", ", "_")
 
 
-def main(fetch_db, write_db, out):
-    f = per_kernel(fetch_db, "FETCH_SIZE")
-    w = per_kernel(write_db, "WRITE_SIZE")
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1",
+def main(fetch_csv, write_csv, out):
+    f = per_kernel(fetch_csv, "FETCH_SIZE")
+    w = per_kernel(write_csv, "WRITE_SIZE")
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1 --no-verify",
            "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-byte read requests as 64 bytes); WRITE_SIZE KiB x 1024",
-           "kernels": {}}
+           "sources_sha256": sources_digest(), "kernels": {}}
     for name in sorted(set(f) | set(w)):
         fb = f.get(name, (0, 0.0))[1] * 1024 * 2
         wb = w.get(name, (0, 0.0))[1] * 1024
