@@ -59,7 +59,14 @@ enum pqd_encoding {
                                       most 256 miniblocks, else PQD_DECODE; parquet-java's writers use 4
                                       miniblocks of 32 values: 256 bytes at most */
   PQD_ENC_BYTE_STREAM_SPLIT = 4,   /* -> elem_size-byte elements */
-  PQD_ENC_BIT_PACKED = 5           /* legacy MSB-first levels -> int32 */
+  PQD_ENC_BIT_PACKED = 5,          /* legacy MSB-first levels -> int32 */
+  PQD_ENC_PLAIN = 6,               /* fixed-width PLAIN values: elem_size-byte elements, 1..16 (INT32 / INT64 / FLOAT /
+                                      DOUBLE / INT96 / FIXED_LEN_BYTE_ARRAY), copied as they are:
+                                      PlainValuesReader.java:38-145, FixedLenByteArrayPlainValuesReader.java.
+                                      A page with fewer than num_values values: PQD_DECODE behind the last whole one */
+  PQD_ENC_PLAIN_BOOLEAN = 7        /* PLAIN booleans, bit (i & 7) of byte (i >> 3): BooleanPlainValuesReader.java:38-89
+                                      -> one byte (0 / 1) per value (elem_size 1) or one int32 (elem_size 4);
+                                      bytes_consumed = min(ceil(num_values / 8), data_len) */
 };
 
 /* pqd_page_desc.flags */
@@ -301,6 +308,62 @@ int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_resul
  */
 int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                            int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result);
+
+/* ---- levels -> columnar structure ---------------------------------------------------------------- */
+/*
+ * The reference assembles records value by value: ColumnReaderBase.checkRead takes one repetition and
+ * one definition level per value; the value is present exactly when dl == maxDefinitionLevel and a
+ * record starts where rl == 0 (parquet-column/.../impl/ColumnReaderBase.java:642-668, isNull :322-325).
+ * The three entry points below give a columnar consumer the same facts as arrays, from levels that
+ * pqd_decode_pages_dev (PQD_ENC_RLE / PQD_ENC_BIT_PACKED) has decoded to int32.  All pointers are
+ * DEVICE pointers; descriptor and result arrays are device arrays of n_pages entries; one page per
+ * descriptor.  pqd_page_result.reserved carries the count named below.
+ */
+/* Definition levels -> validity.  validity bit i (LSB first, Arrow's layout; ceil(n_levels / 8) bytes,
+ * padding bits zero) = def_levels[i] == max_def; value_index[i] = position of slot i's value among the
+ * page's non-null values, -1 for a null.  Either output may be NULL.  def_levels NULL = a required
+ * column (max level 0: Encoding.java:122-125, every value present).
+ * result: values_written = n_levels, reserved = number of non-null values (= the values the page's
+ * data section holds: the num_values to decode it with). */
+typedef struct pqd_validity_desc {
+  const int32_t* def_levels;
+  uint8_t* validity;
+  int32_t* value_index;
+  uint32_t n_levels;
+  int32_t max_def;
+} pqd_validity_desc;
+int pqd_def_levels_to_validity_dev(const pqd_validity_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream);
+/* Null scatter: out[i] = validity bit i ? values[rank of i among the set bits] : zero bytes, for n_slots
+ * slots of elem_size bytes (1..16; all pages of a call share it).  validity NULL = all set.
+ * result: values_written = n_slots, reserved = set bits; a set bit whose value lies beyond n_values:
+ * PQD_DECODE, values_written = that slot (slots before it are right, later ones hold zeros where the
+ * values are missing). */
+typedef struct pqd_scatter_desc {
+  const void* values;      /* the page's dense non-null values, n_values of them */
+  const uint8_t* validity; /* n_slots bits */
+  void* out;               /* n_slots elements */
+  uint32_t n_slots;
+  uint32_t n_values;
+} pqd_scatter_desc;
+int pqd_scatter_nulls_dev(const pqd_scatter_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem_size,
+                          void* stream);
+/* Repetition levels -> list offsets, for the outermost repeated level: row r starts at the r-th level
+ * with rl == 0; a level holds an element slot (null or not) when dl >= slot_def; offsets[r] = element
+ * slots before row r, offsets[n_rows] = all of them.  row_valid[r] (optional, one byte per row) = the
+ * definition level at the row's first level >= row_def (the list itself is not null).
+ * result: values_written = n_rows, reserved = element slots.  More rows than rows_capacity:
+ * PQD_BAD_ARG, the first rows_capacity offsets are written. */
+typedef struct pqd_offsets_desc {
+  const int32_t* rep_levels;
+  const int32_t* def_levels;
+  int32_t* offsets;       /* rows_capacity + 1 */
+  uint8_t* row_valid;     /* rows_capacity, or NULL */
+  uint32_t n_levels;
+  uint32_t rows_capacity;
+  int32_t slot_def;
+  int32_t row_def;
+} pqd_offsets_desc;
+int pqd_rep_levels_to_offsets_dev(const pqd_offsets_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,9 +21,9 @@ OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB = 0, 1, 2, 3, 4, 5
 
 def build(force=False):
     """Compile the oracle with gcc (a few hundred ms)."""
-    src = os.path.join(_HERE, "pqd_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libpqd_oracle.so"])
     return _LIB_PATH
 
@@ -78,6 +78,12 @@ def _declare(L):
     L.orc_bss_encode.argtypes = [_u8p, C.c_size_t, C.c_int, _u8p]
     L.orc_bss_encode.restype = None
     L.orc_bitpacked_levels_decode.argtypes = [C.c_int, _u8p, C.c_size_t, _i32p, C.c_size_t, _szp]
+    L.orc_plain_decode.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_size_t, _u8p, _szp]
+    L.orc_plain_boolean_decode.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, _szp, _szp]
+    L.orc_def_validity.argtypes = [_i32p, C.c_size_t, C.c_int32, _u8p, _i32p, _szp]
+    L.orc_def_validity.restype = None
+    L.orc_scatter_nulls.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, _u8p, _szp, _szp]
+    L.orc_rep_offsets.argtypes = [_i32p, _i32p, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, _i32p, _u8p, _szp, _szp]
 
 
 def _u8(a):
@@ -258,3 +264,58 @@ def bitpacked_levels_decode(w, data, n):
     used = C.c_size_t(0)
     st = lib().orc_bitpacked_levels_decode(w, _p(data, _u8p), data.size, _p(out, _i32p), n, C.byref(used))
     return st, out, used.value
+
+
+# ---------------------------------------------------------------- PLAIN pages
+def plain_decode(data, elem, n):
+    data = _u8(data)
+    out = np.zeros(max(n * elem, 1), np.uint8)
+    wr = C.c_size_t(0)
+    st = lib().orc_plain_decode(_p(data, _u8p), data.size, elem, n, _p(out, _u8p), C.byref(wr))
+    return st, out[:wr.value * elem]
+
+
+def plain_boolean_decode(data, n):
+    data = _u8(data)
+    out = np.zeros(max(n, 1), np.uint8)
+    wr, used = C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_plain_boolean_decode(_p(data, _u8p), data.size, n, _p(out, _u8p), C.byref(wr), C.byref(used))
+    return st, out[:wr.value], used.value
+
+
+# ---------------------------------------------------------------- levels -> columnar structure
+def def_validity(def_levels, max_def, n=None):
+    """(validity bitmap bytes, value_index int32[n], non-null count); def_levels None = required column."""
+    if def_levels is None:
+        lv, ptr = None, None
+    else:
+        lv = np.ascontiguousarray(def_levels, np.int32)
+        n = lv.size
+        ptr = _p(lv, _i32p)
+    validity = np.zeros(max((n + 7) // 8, 1), np.uint8)
+    index = np.zeros(max(n, 1), np.int32)
+    cnt = C.c_size_t(0)
+    lib().orc_def_validity(ptr, n, max_def, _p(validity, _u8p), _p(index, _i32p), C.byref(cnt))
+    return validity[:(n + 7) // 8], index[:n], cnt.value
+
+
+def scatter_nulls(values, validity, n_slots, elem):
+    values = _u8(np.ascontiguousarray(values).view(np.uint8))
+    out = np.zeros(max(n_slots * elem, 1), np.uint8)
+    wr, bits = C.c_size_t(0), C.c_size_t(0)
+    vptr = None if validity is None else _p(_u8(validity), _u8p)
+    st = lib().orc_scatter_nulls(_p(values, _u8p), values.size // elem, vptr, n_slots, elem, _p(out, _u8p),
+                                 C.byref(wr), C.byref(bits))
+    return st, out[:n_slots * elem], wr.value, bits.value
+
+
+def rep_offsets(rep, deff, slot_def, row_def, rows_cap):
+    rep = np.ascontiguousarray(rep, np.int32)
+    deff = np.ascontiguousarray(deff, np.int32)
+    offsets = np.zeros(rows_cap + 1, np.int32)
+    row_valid = np.zeros(max(rows_cap, 1), np.uint8)
+    rows, slots = C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_rep_offsets(_p(rep, _i32p), _p(deff, _i32p), rep.size, slot_def, row_def, rows_cap, _p(offsets, _i32p),
+                               _p(row_valid, _u8p), C.byref(rows), C.byref(slots))
+    k = min(rows.value, rows_cap)
+    return st, offsets[:k + 1], row_valid[:k], rows.value, slots.value

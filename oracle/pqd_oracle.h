@@ -92,6 +92,18 @@ void orc_bss_encode(const uint8_t* in, size_t n, int k, uint8_t* out);
 int orc_bitpacked_levels_decode(int w, const uint8_t* in, size_t in_len, int32_t* out, size_t n,
                                 size_t* consumed);
 
+/* ---- PLAIN pages (pqd_oracle_pages.c): PlainValuesReader.java:38-145, BooleanPlainValuesReader.java:38-89 */
+int orc_plain_decode(const uint8_t* in, size_t in_len, int elem, size_t n, uint8_t* out, size_t* written);
+int orc_plain_boolean_decode(const uint8_t* in, size_t in_len, size_t n, uint8_t* out, size_t* written,
+                             size_t* consumed);
+/* ---- decoded levels -> validity / positions, null scatter, list offsets (ColumnReaderBase.java:642-668) */
+void orc_def_validity(const int32_t* def, size_t n, int32_t max_def, uint8_t* validity, int32_t* value_index,
+                      size_t* non_null);
+int orc_scatter_nulls(const uint8_t* values, size_t n_values, const uint8_t* validity, size_t n_slots, int elem,
+                      uint8_t* out, size_t* written, size_t* set_bits);
+int orc_rep_offsets(const int32_t* rep, const int32_t* def, size_t n, int32_t slot_def, int32_t row_def, size_t rows_cap,
+                    int32_t* offsets, uint8_t* row_valid, size_t* n_rows, size_t* n_slots);
+
 /* ---- BytesUtils helpers (parquet-common BytesUtils.java:202-269), exposed for tests */
 int orc_read_uvarint32(const uint8_t* in, size_t len, size_t* pos, uint32_t* v);
 int orc_read_zigzag_varlong(const uint8_t* in, size_t len, size_t* pos, int64_t* v);

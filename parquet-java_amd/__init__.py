@@ -17,13 +17,13 @@ import numpy as _np
 
 from . import _native
 from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
-                      ENC_DELTA_BINARY_PACKED, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
+                      ENC_DELTA_BINARY_PACKED, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
                       HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
-                      BinaryPageDesc, DictInfo, PageDesc, PageResult, PqdError, check, lib)
+                      BinaryPageDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
-           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader",
+           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
 
@@ -600,6 +600,62 @@ class ByteBitPackingValuesReader(ValuesReader):
 
 
 # ------------------------------------------------------------------------------- device-resident batches
+class PlainValuesReader(ValuesReader):
+    """PlainValuesReader.{Integer,Long,Float,Double}PlainValuesReader (parquet-column/.../values/plain/
+    PlainValuesReader.java:38-145): initFromPage takes everything that is available, each read returns the
+    next little-endian value, a read past the end raises ParquetDecodingException("could not read ...")."""
+    _encoding = ENC_PLAIN
+
+    def __init__(self, dtype):
+        self._dtype = _np.dtype(dtype)
+        super().__init__()
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("could not read " + {"int32": "int", "int64": "long", "float32": "float",
+                                                             "float64": "double"}.get(self._dtype.name, "value"))
+
+    def skip(self, n=1):
+        if self._i + n > len(self._values) or n < 0:
+            raise ParquetDecodingException("could not skip %d values" % n)
+        self._i += n
+
+    class IntegerPlainValuesReader:
+        def __new__(cls):
+            return PlainValuesReader(_np.int32)
+
+    class LongPlainValuesReader:
+        def __new__(cls):
+            return PlainValuesReader(_np.int64)
+
+    class FloatPlainValuesReader:
+        def __new__(cls):
+            return PlainValuesReader(_np.float32)
+
+    class DoublePlainValuesReader:
+        def __new__(cls):
+            return PlainValuesReader(_np.float64)
+
+
+class BooleanPlainValuesReader(ValuesReader):
+    """BooleanPlainValuesReader (parquet-column/.../values/plain/BooleanPlainValuesReader.java:38-89): one bit
+    per value, LSB first; the page is min(ceil(valueCount / 8), available) bytes long."""
+    _encoding = ENC_PLAIN_BOOLEAN
+    _dtype = _np.uint8
+
+    def _consume(self, stream, r, start):
+        stream.skipFully(r.bytes_consumed)
+        self._next_offset = start + r.bytes_consumed
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("attempt to read beyond end of boolean page")
+
+    def readBoolean(self):
+        return bool(self._next())
+
+    def skip(self, n=1):
+        self._i += n  # the reference only moves its bit index; a later read fails
+
+
 def make_descs(pages):
     """Builds a host array of ``PageDesc`` from dicts with keys data/out/dict (device addresses as
     ints), data_len, num_values, dict_len, encoding, elem_size, bit_width, flags."""

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("PQD_LIB_PATH") or os.path.join(_HERE, "lib", "libpqde
 
 OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
+ENC_PLAIN, ENC_PLAIN_BOOLEAN = 6, 7
 F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
 TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 1, 2, 3, 4, 5, 6, 7
 VIEW_INVALID = 0xFFFFFFFFFFFFFFFF
@@ -44,7 +45,23 @@ class BinaryPageDesc(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class ValidityDesc(C.Structure):
+    _fields_ = [("def_levels", C.c_void_p), ("validity", C.c_void_p), ("value_index", C.c_void_p),
+                ("n_levels", C.c_uint32), ("max_def", C.c_int32)]
+
+
+class ScatterDesc(C.Structure):
+    _fields_ = [("values", C.c_void_p), ("validity", C.c_void_p), ("out", C.c_void_p),
+                ("n_slots", C.c_uint32), ("n_values", C.c_uint32)]
+
+
+class OffsetsDesc(C.Structure):
+    _fields_ = [("rep_levels", C.c_void_p), ("def_levels", C.c_void_p), ("offsets", C.c_void_p), ("row_valid", C.c_void_p),
+                ("n_levels", C.c_uint32), ("rows_capacity", C.c_uint32), ("slot_def", C.c_int32), ("row_def", C.c_int32)]
+
+
 assert C.sizeof(PageDesc) == 40 and C.sizeof(PageResult) == 16 and C.sizeof(BinaryPageDesc) == 48
+assert C.sizeof(ValidityDesc) == 32 and C.sizeof(ScatterDesc) == 32 and C.sizeof(OffsetsDesc) == 48
 
 EXPORTS = {
     "pqd_version": ([], C.c_int),
@@ -87,6 +104,9 @@ EXPORTS = {
     "pqd_dict_get": ([C.c_void_p, C.POINTER(DictInfo)], C.c_int),
     "pqd_dict_destroy": ([C.c_void_p], C.c_int),
     "pqd_binary_materialize_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_def_levels_to_validity_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_scatter_nulls_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
+    "pqd_rep_levels_to_offsets_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_binary_page": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.POINTER(PageResult)], C.c_int),
 }

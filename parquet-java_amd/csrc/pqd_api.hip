@@ -327,7 +327,7 @@ bool use_planned_rle_path() {
 }
 
 int class_of(const pqd_page_desc& d) {  // pages that can share a launch
-  return ((int)d.encoding << 8) | (int)(d.encoding == PQD_ENC_BYTE_STREAM_SPLIT ? 0 : d.elem_size);
+  return ((int)d.encoding << 8) | (int)(d.encoding == PQD_ENC_BYTE_STREAM_SPLIT || d.encoding == PQD_ENC_PLAIN ? 0 : d.elem_size);
 }
 
 }  // namespace
@@ -617,9 +617,40 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
       if (elem_size != 4) return fail(PQD_BAD_ARG, "PQD_ENC_BIT_PACKED produces 4-byte values");
       PQD_HIP(pqd::launch_bitpacked_pages(descs, results, n_pages, s));
       return PQD_OK;
+    case PQD_ENC_PLAIN:
+      if (elem_size < 1 || elem_size > 16) return fail(PQD_BAD_ARG, "PLAIN elements are 1..16 bytes");
+      PQD_HIP(pqd::launch_plain_pages(descs, results, n_pages, s));
+      return PQD_OK;
+    case PQD_ENC_PLAIN_BOOLEAN:
+      if (elem_size != 1 && elem_size != 4) return fail(PQD_BAD_ARG, "PLAIN booleans decode to 1- or 4-byte values");
+      PQD_HIP(pqd::launch_plain_boolean_pages(descs, results, n_pages, elem_size, s));
+      return PQD_OK;
     default:
       return fail(PQD_BAD_ARG, "unknown encoding");
   }
+}
+
+int pqd_def_levels_to_validity_dev(const pqd_validity_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  PQD_HIP(pqd::launch_def_validity(descs, results, n_pages, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_scatter_nulls_dev(const pqd_scatter_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem_size,
+                          void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  if (elem_size < 1 || elem_size > 16) return fail(PQD_BAD_ARG, "elements are 1..16 bytes");
+  PQD_HIP(pqd::launch_scatter_nulls(descs, results, n_pages, elem_size, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_rep_levels_to_offsets_dev(const pqd_offsets_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  PQD_HIP(pqd::launch_rep_offsets(descs, results, n_pages, as_stream(stream)));
+  return PQD_OK;
 }
 
 int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int encoding,

@@ -41,6 +41,14 @@ hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results
                             hipStream_t stream);
 hipError_t launch_bitpacked_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                                   hipStream_t stream);
+hipError_t launch_plain_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
+hipError_t launch_plain_boolean_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
+                                      hipStream_t stream);
+// decoded levels -> validity bitmap / value positions, null scatter, list offsets (one workgroup per page)
+hipError_t launch_def_validity(const pqd_validity_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
+hipError_t launch_scatter_nulls(const pqd_scatter_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
+                                hipStream_t stream);
+hipError_t launch_rep_offsets(const pqd_offsets_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 // BINARY values gathered from their views into offsets + bytes, one workgroup per page
 hipError_t launch_binary_pages(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                                hipStream_t stream);

@@ -24,6 +24,7 @@ FILES = [
     "parquet-hadoop/src/test/resources/test-append_2.parquet",
     "parquet-hadoop/src/test/resources/test-file-with-no-column-indexes-1.parquet",
 ]
+PLAIN_FMT = {"INT32": ("i", 4), "INT64": ("q", 8), "DOUBLE": ("d", 8), "FLOAT": ("f", 4)}
 ENCODINGS = {0: "PLAIN", 2: "PLAIN_DICTIONARY", 3: "RLE", 4: "BIT_PACKED", 5: "DELTA_BINARY_PACKED",
              8: "RLE_DICTIONARY", 9: "BYTE_STREAM_SPLIT"}
 
@@ -158,6 +159,7 @@ def main():
                 page_no = 0
                 decoded_strings = []
                 def_levels_all = []
+                plain_values = []
                 while pos < end:
                     h, body = read_page_header(buf, pos)
                     size = h[3]
@@ -210,6 +212,15 @@ def main():
                                              dictionary=[d.decode("latin-1") for d in dictionary],
                                              dictionary_page=dictionary_page.hex()))
                         decoded_strings += [dictionary[i] for i in ids]
+                    elif enc == "PLAIN" and cc.physical_type in PLAIN_FMT:
+                        # PLAIN fixed-width values as parquet-java wrote them: n_present little-endian values
+                        fmt, size = PLAIN_FMT[cc.physical_type]
+                        sect = payload[q:]
+                        vals = list(struct.unpack_from("<%d%s" % (n_present, fmt), sect, 0))
+                        fixtures.append(dict(base, kind="plain_values", encoding="PLAIN", physical_type=cc.physical_type,
+                                             elem_size=size, data=bytes(sect).hex(), num_values=n_present,
+                                             expected_hex=bytes(sect[:n_present * size]).hex()))
+                        plain_values += vals
                     page_no += 1
                 # ---- cross-checks against pyarrow's reading of the same chunk
                 name = cc.path_in_schema
@@ -225,6 +236,13 @@ def main():
                     f = name.split(".")[1]
                     exp = [0 if v is None else (1 if v[f] is None else 2) for v in arr]
                     assert exp == def_levels_all, name
+                if plain_values and max_rep == 0:
+                    if "." not in name:
+                        arr = table.column(name).slice(row0, g.num_rows).to_pylist()
+                    else:
+                        top, f = name.split(".")
+                        arr = [None if v is None else v[f] for v in table.column(top).slice(row0, g.num_rows).to_pylist()]
+                    assert [v for v in arr if v is not None] == plain_values, name
                 if decoded_strings and name == "phoneNumbers.phone.kind":
                     arr = table.column("phoneNumbers").slice(row0, g.num_rows).to_pylist()
                     flat = [p["kind"].encode() for v in arr if v is not None and v["phone"] is not None

@@ -24,6 +24,11 @@ def test_fixture_file_is_populated():
 def test_oracle_decodes_java_written_pages(orc):
     for f in fixtures():
         data = np.frombuffer(bytes.fromhex(f["data"]), np.uint8)
+        if f["kind"] == "plain_values":
+            st, vals = orc.plain_decode(data, f["elem_size"], f["num_values"])
+            assert st == 0 and vals.tobytes().hex() == f["expected_hex"], f["column"]
+            assert orc.plain_decode(data, f["elem_size"], f["num_values"] + 1)[0] == orc.DECODE  # "could not read ..."
+            continue
         exp = np.array(f["expected"], np.int32)
         if f["kind"] == "dictionary_ids":
             st, ids = orc.dict_decode_ids(data, exp.size)
@@ -46,7 +51,7 @@ def test_gpu_decodes_java_written_pages(orc, dict_path, rle_path):
     import gpu_harness as gh
     pq.init(0)
     fx = fixtures()
-    levels = [f for f in fx if f["kind"] != "dictionary_ids" and f["encoding"] == "RLE"]
+    levels = [f for f in fx if f["kind"] in ("def_levels", "rep_levels") and f["encoding"] == "RLE"]
     pages = [gh.Page(bytes.fromhex(f["data"]), len(f["expected"]), pq.ENC_RLE, 4, bit_width=f["bit_width"],
                      flags=pq.F_LENGTH_PREFIX) for f in levels]
     for f, (st, written, consumed, out, guard) in zip(levels, gh.decode_pages(pages)):
@@ -64,3 +69,18 @@ def test_gpu_decodes_java_written_pages(orc, dict_path, rle_path):
             exp.append(lens[np.array(f["expected"])])
         for e, (st, written, consumed, out, guard) in zip(exp, gh.decode_pages(pages)):
             assert st == 0 and written == e.size and (out.view(dt) == e).all()
+    # PLAIN pages: INT32 / INT64 / DOUBLE values as parquet-java wrote them, one launch for all element sizes
+    plain = [f for f in fx if f["kind"] == "plain_values"]
+    assert len(plain) >= 20
+    for elem in (4, 8):
+        sel = [f for f in plain if f["elem_size"] == elem]
+        pages = [gh.Page(bytes.fromhex(f["data"]), f["num_values"], pq.ENC_PLAIN, elem) for f in sel]
+        pages += [gh.Page(bytes.fromhex(f["data"]), f["num_values"] + 3, pq.ENC_PLAIN, elem) for f in sel[:4]]  # reads past the end
+        res = gh.decode_pages(pages)
+        for f, (st, written, consumed, out, guard) in zip(sel, res):
+            assert st == 0 and written == f["num_values"] and consumed == len(f["data"]) // 2
+            assert out.tobytes().hex() == f["expected_hex"], f["column"]
+            assert (guard == 0xA5).all()
+        for f, (st, written, consumed, out, guard) in zip(sel[:4], res[len(sel):]):
+            assert st == pq.DECODE and written == f["num_values"]
+            assert out[:written * elem].tobytes().hex() == f["expected_hex"]
