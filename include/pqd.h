@@ -365,6 +365,103 @@ typedef struct pqd_offsets_desc {
 } pqd_offsets_desc;
 int pqd_rep_levels_to_offsets_dev(const pqd_offsets_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream);
 
+/* ---- column chunks: page headers -> page table -> descriptors ------------------------------------- */
+/*
+ * HOST.  Walks the pages of one column chunk: replaces ParquetFileReader.Chunk.readAllPages
+ * (parquet-hadoop/.../hadoop/ParquetFileReader.java:1973-2117) up to, but not including, decompression.
+ * `chunk` = the chunk's bytes from its first page header (dictionary page first, if there is one);
+ * value_count = ColumnChunkMetaData.getValueCount(): pages are read while fewer values have been seen
+ * (hasMorePages, :2130-2134); -1 = until the bytes are used up.  Each page's thrift compact PageHeader
+ * (parquet-format PageHeader / DataPageHeader / DictionaryPageHeader / DataPageHeaderV2) is parsed into
+ * one pqd_chunk_page; pages of other types (INDEX_PAGE) are skipped as the reference skips them.
+ * verify_crc != 0: a page whose header carries a crc is checked (CRC-32 of the page bytes as stored;
+ * V2: repetition levels + definition levels + values), as with usePageChecksumVerification (:2021-2046).
+ * Errors (Java: IOException / ParquetDecodingException): PQD_EOF header or page runs past the chunk;
+ * PQD_DECODE malformed header, a second dictionary page ("more than one dictionary page in column"),
+ * CRC mismatch, negative sizes, level lengths beyond the page, or a value count that does not add up
+ * ("Expected N values in column chunk ... but got M").  PQD_BAD_ARG: more pages than pages_capacity
+ * (n_pages then holds the number needed).
+ */
+enum pqd_page_type { PQD_PAGE_DATA = 0, PQD_PAGE_INDEX = 1, PQD_PAGE_DICTIONARY = 2, PQD_PAGE_DATA_V2 = 3 };
+/* org.apache.parquet.format.Encoding numbering, as page headers carry it */
+enum pqd_format_encoding {
+  PQD_FMT_PLAIN = 0, PQD_FMT_PLAIN_DICTIONARY = 2, PQD_FMT_RLE = 3, PQD_FMT_BIT_PACKED = 4,
+  PQD_FMT_DELTA_BINARY_PACKED = 5, PQD_FMT_DELTA_LENGTH_BYTE_ARRAY = 6, PQD_FMT_DELTA_BYTE_ARRAY = 7,
+  PQD_FMT_RLE_DICTIONARY = 8, PQD_FMT_BYTE_STREAM_SPLIT = 9
+};
+typedef struct pqd_chunk_page {
+  uint32_t header_offset;     /* of the page header in the chunk                                        */
+  uint32_t body_offset;       /* of the page bytes behind it                                            */
+  uint32_t compressed_size;   /* bytes stored (PageHeader.compressed_page_size)                         */
+  uint32_t uncompressed_size; /* PageHeader.uncompressed_page_size                                      */
+  uint32_t num_values;        /* incl. nulls (data pages); dictionary entries (dictionary page)         */
+  uint32_t num_nulls;         /* V2                                                                     */
+  uint32_t num_rows;          /* V2                                                                     */
+  uint32_t rep_levels_len;    /* V2: repetition_levels_byte_length                                      */
+  uint32_t def_levels_len;    /* V2: definition_levels_byte_length                                      */
+  uint32_t crc;               /* valid when has_crc                                                     */
+  uint8_t type;               /* enum pqd_page_type                                                     */
+  uint8_t encoding;           /* enum pqd_format_encoding of the values                                 */
+  uint8_t def_encoding;       /* V1 (V2: RLE)                                                           */
+  uint8_t rep_encoding;       /* V1 (V2: RLE)                                                           */
+  uint8_t is_compressed;      /* V2: DataPageHeaderV2.is_compressed (default true); V1 / dictionary: 1  */
+  uint8_t has_crc;
+  uint8_t reserved[2];
+} pqd_chunk_page;
+int pqd_chunk_walk(const uint8_t* chunk, size_t chunk_len, int64_t value_count, int verify_crc, pqd_chunk_page* pages,
+                   uint32_t pages_capacity, uint32_t* n_pages);
+/* CRC-32 (java.util.zip.CRC32, the polynomial of zlib) of `len` bytes, continuing from `crc` (0 to start). HOST. */
+uint32_t pqd_crc32(uint32_t crc, const uint8_t* data, size_t len);
+
+/*
+ * What ColumnReaderBase.readPageV1 / readPageV2 / initDataReader do with a page once it is uncompressed
+ * (parquet-column/.../impl/ColumnReaderBase.java:693-780), for all data pages of a chunk at once and
+ * on the DEVICE: each page's body is cut into repetition levels, definition levels and values and the
+ * three decode descriptors are written.  V1: the level sections carry their own 4-byte lengths (RLE,
+ * RunLengthBitPackingHybridValuesReader.java:41-45) or are ceil(num_values * width / 8) bytes
+ * (BIT_PACKED, ByteBitPackingValuesReader.java:78-85), read from the body on the device; V2: lengths
+ * from the header, no prefix (:751-780).  A level of maximum 0 has no bytes (Encoding.java:122-125).
+ *   sections[i]   page table entry i (DEVICE copy of the data pages of pqd_chunk_walk, dictionary page
+ *                 left out) with body_offset = offset of the page's UNCOMPRESSED body in `bodies`
+ *   rep / def     descriptors of the level streams -> int32 levels at rep_out / def_out + first value
+ *                 index of the page (level_base[i], in values); encoding PQD_ENC_RLE or PQD_ENC_BIT_PACKED,
+ *                 data_len 0 for a level of maximum 0 (such a page's levels are all zero: the caller
+ *                 clears the outputs once)
+ *   val           descriptor of the values: encoding and element size from the page's encoding and the
+ *                 column's physical type; num_values = the page's value count incl. nulls (an upper
+ *                 bound; pqd_chunk_set_value_counts_dev lowers it to the non-null count once the
+ *                 definition levels are decoded); out = val_out + value_base[i] * elem_size;
+ *                 dict / dict_len as given.  Encodings this library does not decode (the BYTE_ARRAY
+ *                 ones) give encoding 0: such a descriptor is rejected by pqd_decode_pages_dev.
+ * results[i].status: PQD_OK, or PQD_EOF / PQD_DECODE when a level section runs past the page.
+ */
+typedef struct pqd_column_meta {
+  int32_t physical_type; /* enum pqd_physical_type; BOOLEAN = 0                                          */
+  int32_t type_length;   /* FIXED_LEN_BYTE_ARRAY                                                         */
+  int32_t max_def;       /* ColumnDescriptor.getMaxDefinitionLevel()                                     */
+  int32_t max_rep;       /* ColumnDescriptor.getMaxRepetitionLevel()                                     */
+} pqd_column_meta;
+#define PQD_TYPE_BOOLEAN 0
+typedef struct pqd_chunk_outputs {
+  const uint8_t* bodies;        /* DEVICE: the uncompressed page bodies                                  */
+  int32_t* rep_out;             /* DEVICE: int32 levels of the whole chunk (NULL when max_rep == 0)      */
+  int32_t* def_out;             /* likewise                                                              */
+  void* val_out;                /* DEVICE: dense non-null values of the whole chunk                      */
+  const uint32_t* level_base;   /* DEVICE: per page, index of its first level in rep_out / def_out       */
+  const uint32_t* value_base;   /* DEVICE: per page, index of its first value in val_out (an upper bound
+                                   layout: level_base works when nulls leave gaps; see the set-counts call) */
+  const void* dict;             /* DEVICE: dictionary entries (pqd_dict_info.entries) or NULL            */
+  uint32_t dict_len;
+  uint32_t reserved;
+} pqd_chunk_outputs;
+int pqd_chunk_sections_dev(const pqd_chunk_page* sections, uint32_t n_pages, const pqd_column_meta* column,
+                           const pqd_chunk_outputs* outputs, pqd_page_desc* rep_descs, pqd_page_desc* def_descs,
+                           pqd_page_desc* val_descs, pqd_page_result* results, void* stream);
+/* Sets val_descs[i].num_values to the number of non-null values of page i, as the validity results
+ * (pqd_def_levels_to_validity_dev: pqd_page_result.reserved) report it.  DEVICE arrays. */
+int pqd_chunk_set_value_counts_dev(pqd_page_desc* val_descs, const pqd_page_result* validity_results, uint32_t n_pages,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

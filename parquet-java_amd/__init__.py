@@ -18,9 +18,9 @@ import numpy as _np
 from . import _native
 from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
                       ENC_DELTA_BINARY_PACKED, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
-                      HIP_ERROR, NO_DEVICE, OK, PAST_END, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
+                      HIP_ERROR, NO_DEVICE, OK, PAGE_DATA, PAGE_DATA_V2, PAGE_DICTIONARY, PAGE_INDEX, PAST_END, TYPE_BOOLEAN, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
-                      BinaryPageDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
+                      BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
            "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",

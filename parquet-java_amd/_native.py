@@ -19,7 +19,8 @@ OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
 ENC_PLAIN, ENC_PLAIN_BOOLEAN = 6, 7
 F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
-TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 1, 2, 3, 4, 5, 6, 7
+TYPE_BOOLEAN, TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 0, 1, 2, 3, 4, 5, 6, 7
+PAGE_DATA, PAGE_INDEX, PAGE_DICTIONARY, PAGE_DATA_V2 = 0, 1, 2, 3
 VIEW_INVALID = 0xFFFFFFFFFFFFFFFF
 
 
@@ -60,7 +61,26 @@ class OffsetsDesc(C.Structure):
                 ("n_levels", C.c_uint32), ("rows_capacity", C.c_uint32), ("slot_def", C.c_int32), ("row_def", C.c_int32)]
 
 
+class ChunkPage(C.Structure):
+    _fields_ = [("header_offset", C.c_uint32), ("body_offset", C.c_uint32), ("compressed_size", C.c_uint32),
+                ("uncompressed_size", C.c_uint32), ("num_values", C.c_uint32), ("num_nulls", C.c_uint32),
+                ("num_rows", C.c_uint32), ("rep_levels_len", C.c_uint32), ("def_levels_len", C.c_uint32), ("crc", C.c_uint32),
+                ("type", C.c_uint8), ("encoding", C.c_uint8), ("def_encoding", C.c_uint8), ("rep_encoding", C.c_uint8),
+                ("is_compressed", C.c_uint8), ("has_crc", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class ColumnMeta(C.Structure):
+    _fields_ = [("physical_type", C.c_int32), ("type_length", C.c_int32), ("max_def", C.c_int32), ("max_rep", C.c_int32)]
+
+
+class ChunkOutputs(C.Structure):
+    _fields_ = [("bodies", C.c_void_p), ("rep_out", C.c_void_p), ("def_out", C.c_void_p), ("val_out", C.c_void_p),
+                ("level_base", C.c_void_p), ("value_base", C.c_void_p), ("dict", C.c_void_p), ("dict_len", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 assert C.sizeof(PageDesc) == 40 and C.sizeof(PageResult) == 16 and C.sizeof(BinaryPageDesc) == 48
+assert C.sizeof(ChunkPage) == 48 and C.sizeof(ColumnMeta) == 16 and C.sizeof(ChunkOutputs) == 64
 assert C.sizeof(ValidityDesc) == 32 and C.sizeof(ScatterDesc) == 32 and C.sizeof(OffsetsDesc) == 48
 
 EXPORTS = {
@@ -107,6 +127,11 @@ EXPORTS = {
     "pqd_def_levels_to_validity_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_scatter_nulls_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "pqd_rep_levels_to_offsets_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_chunk_walk": ([C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.POINTER(ChunkPage), C.c_uint32, C.POINTER(C.c_uint32)], C.c_int),
+    "pqd_crc32": ([C.c_uint32, C.c_void_p, C.c_size_t], C.c_uint32),
+    "pqd_chunk_sections_dev": ([C.c_void_p, C.c_uint32, C.POINTER(ColumnMeta), C.POINTER(ChunkOutputs), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "pqd_chunk_set_value_counts_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_binary_page": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.POINTER(PageResult)], C.c_int),
 }

@@ -249,6 +249,28 @@ def main():
                             for p in v["phone"] if p["kind"] is not None]
                     assert flat == decoded_strings, name
             row0 += g.num_rows
+    # whole column chunks of the same files (page headers included), for the page-header walk
+    import base64
+    chunks = []
+    for rel in FILES + ["parquet-avro/src/test/resources/strings-2.parquet"]:
+        path = os.path.join(REF, rel)
+        buf = open(path, "rb").read()
+        pf = pq.ParquetFile(path)
+        md = pf.metadata
+        for rg in range(md.num_row_groups):
+            g = md.row_group(rg)
+            for ci in range(md.num_columns):
+                cc = g.column(ci)
+                col = pf.schema.column(ci)
+                start = cc.data_page_offset if cc.dictionary_page_offset is None else min(cc.dictionary_page_offset, cc.data_page_offset)
+                chunks.append(dict(file=os.path.basename(rel), row_group=rg, column=cc.path_in_schema, created_by=md.created_by,
+                                   physical_type=cc.physical_type, max_def=col.max_definition_level, max_rep=col.max_repetition_level,
+                                   codec=cc.compression, num_values=cc.num_values, has_dictionary_page=cc.has_dictionary_page,
+                                   encodings=list(cc.encodings), chunk=base64.b64encode(buf[start:start + cc.total_compressed_size]).decode()))
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "java_chunks.json")
+    with open(out, "w") as f:
+        json.dump(dict(source="column chunks of parquet-java test resources", fixtures=chunks), f, separators=(",", ":"))
+    print("wrote", out, os.path.getsize(out), "bytes;", len(chunks), "column chunks")
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "java_pages.json")
     with open(out, "w") as f:
         json.dump(dict(source="parquet-java test resources: " + ", ".join(FILES), fixtures=fixtures), f, separators=(",", ":"))

@@ -100,6 +100,9 @@ def tables():
                                                  "dba_sorted": "DELTA_BYTE_ARRAY", "dlba_opt": "DELTA_LENGTH_BYTE_ARRAY"}), \
         pa.table({"dlba": strs, "dba": strs, "dba_sorted": sorted_strs, "dlba_opt": with_nulls(strs, rng, 0.2, pa.string())})
     comp = {"i64": ts, "str": strs, "f64_opt": with_nulls(f64, rng, 0.2, pa.float64()), "runs": np.repeat(rng.integers(0, 5, n // 50), 50).astype(np.int32)}
+    for ver in ("1.0", "2.0"):  # page checksums (PageHeader.crc), plain and compressed
+        yield "crc_v%s" % ver[0], dict(data_page_version=ver, compression={"i64": "NONE", "str": "SNAPPY", "f64_opt": "NONE", "runs": "ZSTD"},
+                                      use_dictionary=["str", "runs"], data_page_size=4096, write_page_checksum=True), pa.table(comp)
     for codec in ("SNAPPY", "ZSTD", "LZ4_RAW"):
         for ver in ("1.0", "2.0"):
             yield "comp_%s_v%s" % (codec.lower(), ver[0]), dict(data_page_version=ver, compression=codec, use_dictionary=["str", "runs"],

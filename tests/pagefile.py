@@ -49,7 +49,8 @@ class Compact:
         elif t == 7:
             self.p += 8
         elif t == 8:
-            self.p += self.varint()
+            n = self.varint()
+            self.p += n
         elif t in (9, 10):
             h = self.byte()
             n = h >> 4
