@@ -64,9 +64,11 @@ enum pqd_encoding {
                                       DOUBLE / INT96 / FIXED_LEN_BYTE_ARRAY), copied as they are:
                                       PlainValuesReader.java:38-145, FixedLenByteArrayPlainValuesReader.java.
                                       A page with fewer than num_values values: PQD_DECODE behind the last whole one */
-  PQD_ENC_PLAIN_BOOLEAN = 7        /* PLAIN booleans, bit (i & 7) of byte (i >> 3): BooleanPlainValuesReader.java:38-89
+  PQD_ENC_PLAIN_BOOLEAN = 7,       /* PLAIN booleans, bit (i & 7) of byte (i >> 3): BooleanPlainValuesReader.java:38-89
                                       -> one byte (0 / 1) per value (elem_size 1) or one int32 (elem_size 4);
                                       bytes_consumed = min(ceil(num_values / 8), data_len) */
+  PQD_ENC_DELTA_LENGTH_BYTE_ARRAY = 8, /* pqd_delta_byte_array_dev only */
+  PQD_ENC_DELTA_BYTE_ARRAY = 9         /* pqd_delta_byte_array_dev only */
 };
 
 /* pqd_page_desc.flags */
@@ -308,6 +310,58 @@ int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_resul
  */
 int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                            int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result);
+
+/* ---- DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY value pages ------------------------------------------ */
+/*
+ * Replaces the read loops over DeltaLengthByteArrayValuesReader (parquet-column/.../values/
+ * deltalengthbytearray/DeltaLengthByteArrayValuesReader.java:33-77: all lengths as one
+ * DELTA_BINARY_PACKED block, then the values back to back; readBytes slices `length` bytes and fails
+ * with "Failed to read N bytes" when the page ends first) and DeltaByteArrayReader (.../deltastrings/
+ * DeltaByteArrayReader.java:32-95: prefix lengths as one DELTA_BINARY_PACKED block, then a
+ * DELTA_LENGTH_BYTE_ARRAY section of suffixes; value i = first prefix[i] bytes of value i-1 + suffix i.
+ * The prefix of a page's first value refers to the last value of the page before it when the caller
+ * links them, as ColumnReaderBase does through setPreviousReader for files written before PARQUET-246
+ * was fixed; current writers start every page with prefix 0).
+ * Output as for pqd_binary_materialize_dev: offsets[i] = start of value i in `bytes`,
+ * offsets[values_written] = end of the last value delivered = result.reserved; result.bytes_consumed =
+ * page bytes read (length blocks + value bytes).  With bytes == NULL a DELTA_LENGTH_BYTE_ARRAY page is
+ * left where it is (the reference's zero-copy Binary views): value i is
+ * data[bytes_consumed - reserved + offsets[i] ...].
+ * Status: a length block that fails fails the page before its first value (both readers decode their
+ * length blocks in initFromPage); PQD_DECODE at the first value whose length is negative, whose bytes
+ * run past the page, whose prefix is longer than the value before it, or that has no length left in
+ * a block ("no more value to read"); PQD_BAD_ARG at the first value that does not fit into
+ * bytes_capacity (at most 2^31-1).  (A negative length has no defined meaning in the reference: an
+ * empty value from MultiBufferInputStream.slice, a backwards seek from SingleBufferInputStream.slice.)
+ * All pointers are DEVICE pointers.  `work` is scratch of PQD_DELTA_BYTES_WORK(num_values) bytes per
+ * page, 16-byte aligned, that the call overwrites.
+ */
+#define PQD_DELTA_BYTES_WORK(num_values) (64u + 8u * (size_t)(num_values))
+typedef struct pqd_delta_bytes_desc {
+  const uint8_t* data;         /* the page's values section                                          */
+  int32_t* offsets;            /* num_values + 1                                                     */
+  uint8_t* bytes;              /* bytes_capacity                                                     */
+  uint8_t* work;               /* PQD_DELTA_BYTES_WORK(num_values) bytes                             */
+  const int32_t* prev_offsets; /* PQD_ENC_DELTA_BYTE_ARRAY: offsets / bytes of the page decoded      */
+  const uint8_t* prev_bytes;   /* before this one (an earlier call on the same stream); value        */
+                               /* prev_count-1 is the value the first prefix refers to.  NULL: none  */
+  uint32_t data_len;
+  uint32_t num_values;
+  uint32_t bytes_capacity;
+  uint32_t encoding;           /* PQD_ENC_DELTA_LENGTH_BYTE_ARRAY or PQD_ENC_DELTA_BYTE_ARRAY        */
+  uint32_t prev_count;
+  uint32_t reserved;
+} pqd_delta_bytes_desc;
+int pqd_delta_byte_array_dev(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream);
+/*
+ * One such page in HOST memory (what initFromPage + the read loop of the two readers see); `previous`
+ * is the last value of the page before (DELTA_BYTE_ARRAY only, may be NULL / 0).  *bytes_needed (may
+ * be NULL) receives the sum of all lengths in the page's length blocks: the capacity with which a
+ * call that ended in PQD_BAD_ARG succeeds.  Thread-safe like the other host entry points.
+ */
+int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t page_len, uint32_t num_values,
+                                     const uint8_t* previous, uint32_t previous_len, int32_t* offsets, uint8_t* bytes,
+                                     uint32_t bytes_capacity, pqd_page_result* result, uint64_t* bytes_needed);
 
 /* ---- levels -> columnar structure ---------------------------------------------------------------- */
 /*

@@ -84,6 +84,9 @@ def _declare(L):
     L.orc_def_validity.restype = None
     L.orc_scatter_nulls.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, _u8p, _szp, _szp]
     L.orc_rep_offsets.argtypes = [_i32p, _i32p, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, _i32p, _u8p, _szp, _szp]
+    L.orc_delta_length_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp, _szp]
+    L.orc_delta_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp,
+                                       _szp]
 
 
 def _u8(a):
@@ -319,3 +322,29 @@ def rep_offsets(rep, deff, slot_def, row_def, rows_cap):
                                _p(row_valid, _u8p), C.byref(rows), C.byref(slots))
     k = min(rows.value, rows_cap)
     return st, offsets[:k + 1], row_valid[:k], rows.value, slots.value
+
+
+# ---------------------------------------------------------------- DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY
+def delta_length_byte_array(data, n, cap=None):
+    """(status, offsets[written + 1], bytes, consumed) of a DELTA_LENGTH_BYTE_ARRAY values section."""
+    data = _u8(data)
+    cap = data.size if cap is None else cap
+    offsets = np.zeros(n + 1, np.int32)
+    out = np.zeros(max(cap, 1), np.uint8)
+    wr, used, nb = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_delta_length_byte_array(_p(data, _u8p), data.size, n, _p(offsets, _i32p), _p(out, _u8p), cap, C.byref(wr),
+                                           C.byref(used), C.byref(nb))
+    return st, offsets[:wr.value + 1], out[:nb.value], used.value
+
+
+def delta_byte_array(data, n, cap, prev=b""):
+    """(status, offsets[written + 1], bytes, consumed) of a DELTA_BYTE_ARRAY values section."""
+    data = _u8(data)
+    prev = _u8(prev) if len(prev) else np.zeros(1, np.uint8)[:0]
+    offsets = np.zeros(n + 1, np.int32)
+    out = np.zeros(max(cap, 1), np.uint8)
+    wr, used, nb = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    pv = np.ascontiguousarray(np.concatenate([prev, np.zeros(1, np.uint8)]))
+    st = lib().orc_delta_byte_array(_p(data, _u8p), data.size, n, _p(pv, _u8p), prev.size, _p(offsets, _i32p), _p(out, _u8p),
+                                    cap, C.byref(wr), C.byref(used), C.byref(nb))
+    return st, offsets[:wr.value + 1], out[:nb.value], used.value

@@ -104,6 +104,14 @@ int orc_scatter_nulls(const uint8_t* values, size_t n_values, const uint8_t* val
 int orc_rep_offsets(const int32_t* rep, const int32_t* def, size_t n, int32_t slot_def, int32_t row_def, size_t rows_cap,
                     int32_t* offsets, uint8_t* row_valid, size_t* n_rows, size_t* n_slots);
 
+/* ---- DELTA_LENGTH_BYTE_ARRAY (DeltaLengthByteArrayValuesReader.java:44-58) and DELTA_BYTE_ARRAY
+ * (DeltaByteArrayReader.java:50-95) -> offsets + bytes; bytes may be NULL for the first (values stay in the page) */
+int orc_delta_length_byte_array(const uint8_t* in, size_t in_len, size_t n, int32_t* offsets, uint8_t* bytes,
+                                size_t cap, size_t* written, size_t* consumed, size_t* bytes_written);
+int orc_delta_byte_array(const uint8_t* in, size_t in_len, size_t n, const uint8_t* prev, size_t prev_len,
+                         int32_t* offsets, uint8_t* bytes, size_t cap, size_t* written, size_t* consumed,
+                         size_t* bytes_written);
+
 /* ---- BytesUtils helpers (parquet-common BytesUtils.java:202-269), exposed for tests */
 int orc_read_uvarint32(const uint8_t* in, size_t len, size_t* pos, uint32_t* v);
 int orc_read_zigzag_varlong(const uint8_t* in, size_t len, size_t* pos, int64_t* v);

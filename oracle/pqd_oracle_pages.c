@@ -6,6 +6,7 @@
  * (paths relative to the apache/parquet-java tree) and is written the way the Java is: one value
  * at a time.
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include "pqd_oracle.h"
@@ -110,4 +111,129 @@ int orc_rep_offsets(const int32_t* rep, const int32_t* def, size_t n, int32_t sl
   *n_rows = rows;
   *n_slots = slots;
   return rows <= rows_cap ? ORC_OK : ORC_BAD_ARG;
+}
+
+/* ------------------------------------------------------------------------- */
+/* DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY                                    */
+/* ------------------------------------------------------------------------- */
+
+/* One DELTA_BINARY_PACKED block of lengths read as ints: readInteger is (int) readLong
+ * (DeltaBinaryPackingValuesReader.java:96-100).  `cap` bounds the header's count as the value readers
+ * of this library do (the page cannot hold more lengths than it has values). */
+static int read_length_block(const uint8_t* in, size_t in_len, size_t cap, int32_t** lengths, size_t* count,
+                             size_t* consumed) {
+  int64_t* wide = (int64_t*)calloc(cap + 1, sizeof(int64_t));
+  if (!wide) return ORC_DECODE;
+  size_t total = 0;
+  int st = orc_delta_decode(in, in_len, wide, cap, &total, consumed);
+  if (st != ORC_OK) {
+    free(wide);
+    return st;
+  }
+  int32_t* narrow = (int32_t*)calloc(total + 1, sizeof(int32_t));
+  if (!narrow) {
+    free(wide);
+    return ORC_DECODE;
+  }
+  for (size_t i = 0; i < total; ++i) narrow[i] = (int32_t)wide[i];
+  free(wide);
+  *lengths = narrow;
+  *count = total;
+  return ORC_OK;
+}
+
+/* DeltaLengthByteArrayValuesReader.java:44-58: initFromPage reads every length, the values follow back
+ * to back; readBytes takes the next length and slices that many bytes ("Failed to read N bytes" when
+ * the page ends first).  A length block with fewer lengths than the page has values fails the read
+ * behind its last length ("no more value to read", DeltaBinaryPackingValuesReader.java:102-107).  A
+ * negative length is reported as a decode error (the reference's streams disagree on it). */
+int orc_delta_length_byte_array(const uint8_t* in, size_t in_len, size_t n, int32_t* offsets, uint8_t* bytes,
+                                size_t cap, size_t* written, size_t* consumed, size_t* bytes_written) {
+  *written = *consumed = *bytes_written = 0;
+  offsets[0] = 0;
+  int32_t* lengths = NULL;
+  size_t count = 0, header = 0;
+  int st = read_length_block(in, in_len, n, &lengths, &count, &header);
+  if (st != ORC_OK) return st;
+  if (cap > 0x7fffffffu) cap = 0x7fffffffu;
+  size_t pos = header, out = 0, i = 0;
+  for (; i < n; ++i) {
+    offsets[i] = (int32_t)out;
+    if (i >= count) {
+      st = ORC_DECODE;
+      break;
+    }
+    int32_t len = lengths[i];
+    if (len < 0 || (size_t)len > in_len - pos) {
+      st = ORC_DECODE;
+      break;
+    }
+    if (out + (size_t)len > cap) {
+      st = ORC_BAD_ARG;
+      break;
+    }
+    if (bytes) memcpy(bytes + out, in + pos, (size_t)len);
+    pos += (size_t)len;
+    out += (size_t)len;
+  }
+  offsets[i] = (int32_t)out;
+  free(lengths);
+  *written = i;
+  *consumed = pos;
+  *bytes_written = out;
+  return st;
+}
+
+/* DeltaByteArrayReader.java:50-85: initFromPage reads the prefix lengths, then hands the rest of the
+ * page to a DeltaLengthByteArrayValuesReader for the suffixes; readBytes: prefixLength, suffix, and
+ * when prefixLength != 0 the value is previous[0, prefixLength) + suffix (System.arraycopy: a prefix
+ * longer than the previous value is an ArrayIndexOutOfBoundsException), else the suffix itself.
+ * `prev` is the last value of the page before (setPreviousReader, :87-95), or empty. */
+int orc_delta_byte_array(const uint8_t* in, size_t in_len, size_t n, const uint8_t* prev, size_t prev_len,
+                         int32_t* offsets, uint8_t* bytes, size_t cap, size_t* written, size_t* consumed,
+                         size_t* bytes_written) {
+  *written = *consumed = *bytes_written = 0;
+  offsets[0] = 0;
+  int32_t *prefixes = NULL, *suffixes = NULL;
+  size_t n_prefix = 0, n_suffix = 0, used_prefix = 0, used_suffix = 0;
+  int st = read_length_block(in, in_len, n, &prefixes, &n_prefix, &used_prefix);
+  if (st != ORC_OK) return st;
+  st = read_length_block(in + used_prefix, in_len - used_prefix, n, &suffixes, &n_suffix, &used_suffix);
+  if (st != ORC_OK) {
+    free(prefixes);
+    return st;
+  }
+  if (cap > 0x7fffffffu) cap = 0x7fffffffu;
+  size_t pos = used_prefix + used_suffix, out = 0, i = 0;
+  const uint8_t* previous = prev;
+  size_t previous_len = prev ? prev_len : 0;
+  for (; i < n; ++i) {
+    offsets[i] = (int32_t)out;
+    if (i >= n_prefix || i >= n_suffix) {
+      st = ORC_DECODE;
+      break;
+    }
+    int32_t p = prefixes[i], s = suffixes[i];
+    if (p < 0 || s < 0 || (size_t)s > in_len - pos || (size_t)p > previous_len) {
+      st = ORC_DECODE;
+      break;
+    }
+    if (out + (size_t)p + (size_t)s > cap) {
+      st = ORC_BAD_ARG;
+      break;
+    }
+    memmove(bytes + out, previous, (size_t)p);
+    memcpy(bytes + out + (size_t)p, in + pos, (size_t)s);
+    previous = bytes + out;
+    previous_len = (size_t)p + (size_t)s;
+    pos += (size_t)s;
+    out += previous_len;
+  }
+  offsets[i] = (int32_t)out;
+  free(prefixes);
+  free(suffixes);
+  *written = i;
+  *consumed = pos;
+  *bytes_written = out;
+  return st;
 }

@@ -17,13 +17,13 @@ import numpy as _np
 
 from . import _native
 from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
-                      ENC_DELTA_BINARY_PACKED, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
+                      ENC_DELTA_BINARY_PACKED, ENC_DELTA_BYTE_ARRAY, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
                       HIP_ERROR, NO_DEVICE, OK, PAGE_DATA, PAGE_DATA_V2, PAGE_DICTIONARY, PAGE_INDEX, PAST_END, TYPE_BOOLEAN, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
-                      BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
+                      BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DeltaBytesDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
-           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
+           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "DeltaLengthByteArrayValuesReader", "DeltaByteArrayReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
 
@@ -542,6 +542,73 @@ class DeltaBinaryPackingValuesReader(ValuesReader):
         if self._i + n > len(self._values):
             self._fail_at_end()
         self._i += n
+
+
+class DeltaLengthByteArrayValuesReader(ValuesReader):
+    """DeltaLengthByteArrayValuesReader.java:33-77: ``readBytes`` returns the next value; reading past the
+    values the page holds raises ParquetDecodingException ("Failed to read N bytes" / "no more value to
+    read")."""
+    _encoding = ENC_DELTA_LENGTH_BYTE_ARRAY
+
+    def _previous_value(self):
+        return b""
+
+    def initFromPage(self, valueCount, stream):
+        data = _np.ascontiguousarray(stream._peek_all())
+        prev = _np.frombuffer(self._previous_value(), _np.uint8)
+        self._offsets = _np.zeros(valueCount + 1, _np.int32)
+        r, need = PageResult(), _C.c_uint64(0)
+        cap = max(4 * data.size, 1 << 12)
+        while True:
+            self._bytes = _np.zeros(cap, _np.uint8)
+            check(lib.pqd_decode_delta_byte_array_page(self._encoding, _ptr(data), data.size, valueCount,
+                                                       _ptr(prev) if prev.size else None, prev.size, _ptr(self._offsets),
+                                                       _ptr(self._bytes), cap, _C.byref(r), _C.byref(need)),
+                  "pqd_decode_delta_byte_array_page")
+            if r.status != BAD_ARG or need.value <= cap:
+                break
+            cap = need.value  # the lengths asked for more room than the first guess
+        if r.status != OK and r.values_written == 0 and r.bytes_consumed == 0:
+            _raise_for(r.status, type(self).__name__ + ".initFromPage")  # a length block failed
+        self._status = r.status
+        self._values = _np.arange(r.values_written)
+        self._i = 0
+        stream.skipFully(r.bytes_consumed)
+
+    def readBytes(self):
+        i = int(self._next())
+        return self._bytes[self._offsets[i]:self._offsets[i + 1]].tobytes()
+
+    def offsets_and_bytes(self):
+        """Bulk access (not in the reference interface): offsets[n+1] and the value bytes."""
+        n = len(self._values)
+        return self._offsets[:n + 1], self._bytes[:self._offsets[n]]
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("Failed to read the next value: the page holds %d" % len(self._values))
+
+    def skip(self, n=1):
+        for _ in range(n):
+            self._next()
+
+
+class DeltaByteArrayReader(DeltaLengthByteArrayValuesReader):
+    """DeltaByteArrayReader.java:32-95 (prefix lengths, suffixes, the previous value carried from page to
+    page through ``setPreviousReader``)."""
+    _encoding = ENC_DELTA_BYTE_ARRAY
+
+    def __init__(self):
+        super().__init__()
+        self._previous = b""
+
+    def setPreviousReader(self, reader):
+        """:87-95: the last value the previous page's reader delivered."""
+        if reader is not None and len(getattr(reader, "_values", ())):
+            n = len(reader._values)
+            self._previous = reader._bytes[reader._offsets[n - 1]:reader._offsets[n]].tobytes()
+
+    def _previous_value(self):
+        return self._previous
 
 
 class ByteStreamSplitValuesReader(ValuesReader):

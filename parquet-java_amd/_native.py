@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("PQD_LIB_PATH") or os.path.join(_HERE, "lib", "libpqde
 OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
 ENC_PLAIN, ENC_PLAIN_BOOLEAN = 6, 7
+ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY = 8, 9
 F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
 TYPE_BOOLEAN, TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 0, 1, 2, 3, 4, 5, 6, 7
 PAGE_DATA, PAGE_INDEX, PAGE_DICTIONARY, PAGE_DATA_V2 = 0, 1, 2, 3
@@ -59,6 +60,18 @@ class ScatterDesc(C.Structure):
 class OffsetsDesc(C.Structure):
     _fields_ = [("rep_levels", C.c_void_p), ("def_levels", C.c_void_p), ("offsets", C.c_void_p), ("row_valid", C.c_void_p),
                 ("n_levels", C.c_uint32), ("rows_capacity", C.c_uint32), ("slot_def", C.c_int32), ("row_def", C.c_int32)]
+
+
+class DeltaBytesDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("bytes", C.c_void_p), ("work", C.c_void_p),
+                ("prev_offsets", C.c_void_p), ("prev_bytes", C.c_void_p),
+                ("data_len", C.c_uint32), ("num_values", C.c_uint32), ("bytes_capacity", C.c_uint32),
+                ("encoding", C.c_uint32), ("prev_count", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def delta_bytes_work(num_values):
+    """PQD_DELTA_BYTES_WORK: bytes of scratch a delta byte array page needs."""
+    return 64 + 8 * num_values
 
 
 class ChunkPage(C.Structure):
@@ -132,6 +145,9 @@ EXPORTS = {
     "pqd_chunk_sections_dev": ([C.c_void_p, C.c_uint32, C.POINTER(ColumnMeta), C.POINTER(ChunkOutputs), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "pqd_chunk_set_value_counts_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_delta_byte_array_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_decode_delta_byte_array_page": ([C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_uint32, C.POINTER(PageResult), C.POINTER(C.c_uint64)], C.c_int),
     "pqd_decode_binary_page": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.POINTER(PageResult)], C.c_int),
 }

@@ -108,10 +108,10 @@ __device__ __forceinline__ bool quick_block(lds_words_t win, uint32_t off, uint3
   return stop != 0 && !(used & 0x8080808080808080ull) && !((used + 0x3F3F3F3F3F3F3F3Full) & 0x8080808080808080ull);
 }
 
+// One page by one workgroup of DELTA_THREADS threads; `result` gets the page's record (lane 0 writes it).
+// All threads of the workgroup call it together; a second call needs a __syncthreads() in between.
 template <int ELEM>
-__global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_desc* __restrict__ descs,
-                                                               pqd_page_result* __restrict__ results,
-                                                               uint32_t n_pages) {
+__device__ __forceinline__ void delta_page(const pqd_page_desc& d, pqd_page_result* result) {
   typedef typename std::conditional<ELEM == 8, uint64_t, uint32_t>::type acc_t;
   __shared__ u32x4 win4[DWINDOW_PIECES];
   __shared__ uint32_t mini_src[MAX_MINIS];
@@ -123,9 +123,6 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   __shared__ DeltaState st;
   lds_words_t win = (lds_words_t)(const PQD_LDS u32x4*)win4;
 
-  const uint32_t page = blockIdx.x;
-  if (page >= n_pages) return;
-  const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
   const uint32_t end = d.data_len;
   const uint8_t* gend = d.data + end;
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
   if (d.encoding != PQD_ENC_DELTA_BINARY_PACKED || d.elem_size != ELEM) {
     if (tid == 0) {
       pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
-      results[page] = r;
+      *result = r;
     }
     return;
   }
@@ -514,13 +511,66 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_de
       r.values_written = 0;
       r.bytes_consumed = 0;
     }
-    results[page] = r;
+    *result = r;
   }
+}
+
+template <int ELEM>
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_pages(const pqd_page_desc* __restrict__ descs,
+                                                               pqd_page_result* __restrict__ results,
+                                                               uint32_t n_pages) {
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_page_desc d = descs[page];
+  delta_page<ELEM>(d, results + page);
+}
+
+// The length blocks of DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages, decoded into the page's work
+// area: DeltaLengthByteArrayValuesReader.initFromPage reads all lengths first (parquet-column/.../values/
+// deltalengthbytearray/DeltaLengthByteArrayValuesReader.java:44-48), DeltaByteArrayReader.initFromPage
+// reads the prefix lengths and then, from where they end, the suffix lengths (.../deltastrings/
+// DeltaByteArrayReader.java:50-54).  Work area: two result records (32 bytes, padded to 64), the first
+// block's int32 values, then (DELTA_BYTE_ARRAY) the second block's.
+__global__ __launch_bounds__(DELTA_THREADS) void k_delta_length_blocks(const pqd_delta_bytes_desc* __restrict__ descs,
+                                                                       uint32_t n_pages) {
+  __shared__ pqd_page_result first_block;
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_delta_bytes_desc b = descs[page];
+  pqd_page_result* rec = reinterpret_cast<pqd_page_result*>(b.work);
+  int32_t* lengths = reinterpret_cast<int32_t*>(b.work + DELTA_BYTES_WORK_HEADER);
+  pqd_page_desc d{};
+  d.data = b.data;
+  d.out = lengths;
+  d.data_len = b.data_len;
+  d.num_values = b.num_values;
+  d.encoding = PQD_ENC_DELTA_BINARY_PACKED;
+  d.elem_size = 4;
+  delta_page<4>(d, &first_block);
+  __syncthreads();
+  const pqd_page_result r0 = first_block;
+  if (threadIdx.x == 0) rec[0] = r0;
+  if (b.encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;
+  if (r0.status != PQD_OK) {
+    if (threadIdx.x == 0) rec[1] = r0;
+    return;
+  }
+  d.data = b.data + r0.bytes_consumed;
+  d.data_len = b.data_len - r0.bytes_consumed;
+  d.out = lengths + b.num_values;
+  __syncthreads();
+  delta_page<4>(d, rec + 1);
 }
 
 template __global__ void k_delta_pages<4>(const pqd_page_desc*, pqd_page_result*, uint32_t);
 template __global__ void k_delta_pages<8>(const pqd_page_desc*, pqd_page_result*, uint32_t);
 
+
+hipError_t launch_delta_length_blocks(const pqd_delta_bytes_desc* descs, uint32_t n_pages, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_delta_length_blocks, dim3(n_pages), dim3(DELTA_THREADS), 0, stream, descs, n_pages);
+  return hipGetLastError();
+}
 
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream) {

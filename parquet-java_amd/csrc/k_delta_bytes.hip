@@ -1,0 +1,357 @@
+// DELTA_LENGTH_BYTE_ARRAY and DELTA_BYTE_ARRAY value pages -> offsets + bytes.
+//
+// The length blocks are already decoded into the page's work area (k_delta_length_blocks).  What is
+// left of DeltaLengthByteArrayValuesReader.readBytes (parquet-column/.../values/deltalengthbytearray/
+// DeltaLengthByteArrayValuesReader.java:50-58) is a prefix sum of the lengths and one copy of the value
+// bytes, which lie back to back behind the length block: one 256-thread workgroup per page.
+// DeltaByteArrayReader.readBytes (.../deltastrings/DeltaByteArrayReader.java:63-85) builds value i from
+// the first prefix[i] bytes of value i-1 and suffix i, a chain through the whole page.  One wave per
+// page takes 64 values at a time: the suffixes of the batch are staged in LDS, then for every byte
+// column j below the longest prefix one ballot tells each lane the last value at or before it whose
+// own bytes start at or before column j (its suffix holds byte j of every value up to the next such
+// value); columns no value of the batch owns come from the value before the batch, whose leading bytes
+// are kept in LDS.  The assembled values leave through an LDS tile in aligned 16-byte stores.
+// Values or prefixes too long for the tiles are copied one value at a time through global memory.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+
+namespace pqd {
+
+constexpr int DL_THREADS = 256;
+constexpr int DL_PER_LANE = 16;
+constexpr uint32_t DL_TILE = DL_THREADS * DL_PER_LANE;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct LengthBlocks {
+  int32_t status;   // of the length block(s): not PQD_OK fails the page before its first value
+  uint32_t n;       // values that have a length in every block
+  uint32_t header;  // bytes of the length block(s)
+};
+
+__device__ __forceinline__ LengthBlocks length_blocks_of(const pqd_delta_bytes_desc& b) {
+  const pqd_page_result* rec = reinterpret_cast<const pqd_page_result*>(b.work);
+  LengthBlocks lb;
+  const pqd_page_result r0 = rec[0];
+  lb.status = r0.status;
+  lb.n = r0.values_written < b.num_values ? r0.values_written : b.num_values;
+  lb.header = r0.bytes_consumed;
+  if (b.encoding == PQD_ENC_DELTA_BYTE_ARRAY && r0.status == PQD_OK) {
+    const pqd_page_result r1 = rec[1];
+    lb.status = r1.status;
+    lb.n = r1.values_written < lb.n ? r1.values_written : lb.n;
+    lb.header += r1.bytes_consumed;
+  }
+  return lb;
+}
+
+__global__ __launch_bounds__(DL_THREADS) void k_delta_length_bytes(const pqd_delta_bytes_desc* __restrict__ descs,
+                                                                   pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  __shared__ uint64_t wave_totals[DL_THREADS / 64];
+  __shared__ uint32_t s_stop;
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_delta_bytes_desc b = descs[page];
+  if (b.encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY) return;  // the other kernel's page
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const LengthBlocks lb = length_blocks_of(b);
+  if (lb.status != PQD_OK) {
+    if (tid == 0) {
+      b.offsets[0] = 0;
+      pqd_page_result r = {lb.status, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  const int32_t* lengths = reinterpret_cast<const int32_t*>(b.work + DELTA_BYTES_WORK_HEADER);
+  const uint32_t n = lb.n;
+  const uint64_t avail = b.data_len - lb.header;
+  const uint64_t cap = b.bytes ? (b.bytes_capacity > 0x7fffffffu ? 0x7fffffffull : (uint64_t)b.bytes_capacity) : 0x7fffffffull;
+  if (tid == 0) s_stop = NONE;
+  __syncthreads();
+  uint64_t running = 0;
+  uint32_t stop = NONE;
+  int32_t status = PQD_OK;
+  for (uint32_t t0 = 0; t0 < n && stop == NONE; t0 += DL_TILE) {
+    const uint32_t first = t0 + tid * DL_PER_LANE;
+    int32_t len[DL_PER_LANE];
+    uint64_t lane_total = 0;
+    bool negative = false;
+#pragma unroll
+    for (int j = 0; j < DL_PER_LANE; ++j) {
+      len[j] = first + j < n ? lengths[first + j] : 0;
+      negative |= len[j] < 0;
+      lane_total += len[j] < 0 ? 0u : (uint32_t)len[j];
+    }
+    const uint64_t inc = wave_scan_inclusive(lane_total);
+    if (lane == 63) wave_totals[wave] = inc;
+    __syncthreads();
+    uint64_t base = running + inc - lane_total, tile_total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < DL_THREADS / 64; ++k) {
+      const uint64_t wt = wave_totals[k];
+      base += k < wave ? wt : 0u;
+      tile_total += wt;
+    }
+    const uint64_t limit = avail < cap ? avail : cap;
+    if (negative || base + lane_total > limit) {
+      uint64_t at = base;
+#pragma unroll
+      for (int j = 0; j < DL_PER_LANE; ++j) {
+        if (first + j < n && (len[j] < 0 || at + (uint32_t)len[j] > limit)) {
+          atomicMin(&s_stop, first + j);
+          break;
+        }
+        at += (uint32_t)len[j];
+      }
+    }
+    __syncthreads();
+    stop = s_stop;
+    uint64_t at = base;
+#pragma unroll
+    for (int j = 0; j < DL_PER_LANE; ++j) {
+      if (first + j < n && first + j <= stop) b.offsets[first + j] = (int32_t)at;
+      if (first + j == stop) {
+        // this value fails: a broken length or the end of the page (decode error) before the capacity
+        status = (len[j] < 0 || at + (uint32_t)len[j] > avail) ? PQD_DECODE : PQD_BAD_ARG;
+        wave_totals[0] = at;
+        wave_totals[1] = (uint64_t)(uint32_t)status;
+      }
+      at += len[j] < 0 ? 0u : (uint32_t)len[j];
+    }
+    __syncthreads();
+    if (stop != NONE) {
+      running = wave_totals[0];
+      status = (int32_t)wave_totals[1];
+    } else {
+      running += tile_total;
+    }
+    __syncthreads();
+  }
+  const uint32_t written = stop != NONE ? stop : n;
+  if (stop == NONE && n < b.num_values) status = PQD_DECODE;  // "no more value to read" from the length block
+  // the value bytes (they stay in the page when there is no destination)
+  if (b.bytes) {
+    const uint8_t* src = b.data + lb.header;
+    const uint64_t pieces = running >> 4;
+    for (uint64_t i = tid; i < pieces; i += DL_THREADS) {
+      u32x4 v;
+      __builtin_memcpy(&v, src + i * 16, 16);
+      __builtin_memcpy(b.bytes + i * 16, &v, 16);
+    }
+    for (uint64_t i = (pieces << 4) + tid; i < running; i += DL_THREADS) b.bytes[i] = src[i];
+  }
+  if (tid == 0) {
+    if (stop == NONE) b.offsets[n] = (int32_t)running;
+    pqd_page_result r = {status, written, lb.header + (uint32_t)running, (uint32_t)running};
+    results[page] = r;
+  }
+}
+
+// ---- DELTA_BYTE_ARRAY ---------------------------------------------------------------------------------
+
+constexpr uint32_t DB_IN = 8192;    // suffix bytes of a batch staged in LDS
+constexpr uint32_t DB_OUT = 8192;   // assembled bytes of a batch
+constexpr uint32_t DB_KEEP = 1024;  // leading bytes kept of the value before the batch
+
+__device__ __forceinline__ uint32_t shuffle_u32(uint32_t v, uint32_t from_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
+}
+
+__device__ __forceinline__ uint8_t load_written_byte(const uint8_t* p) {
+  // bytes this wave stored a moment ago: read them where the stores went (past the vector L1)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_desc* __restrict__ descs,
+                                                         pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  __shared__ __attribute__((aligned(16))) uint8_t in_tile[DB_IN + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t out_tile[DB_OUT + 32];
+  __shared__ uint8_t keep[DB_KEEP];
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_delta_bytes_desc b = descs[page];
+  if (b.encoding != PQD_ENC_DELTA_BYTE_ARRAY) return;  // the other kernel's page
+  const uint32_t lane = threadIdx.x;
+  const LengthBlocks lb = length_blocks_of(b);
+  if (lb.status != PQD_OK) {
+    if (lane == 0) {
+      b.offsets[0] = 0;
+      pqd_page_result r = {lb.status, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  const int32_t* prefix = reinterpret_cast<const int32_t*>(b.work + DELTA_BYTES_WORK_HEADER);
+  const int32_t* suffix = prefix + b.num_values;
+  const uint32_t n = lb.n;
+  const uint8_t* sdata = b.data + lb.header;
+  const uint64_t savail = b.data_len - lb.header;
+  const uint64_t cap = b.bytes_capacity > 0x7fffffffu ? 0x7fffffffull : (uint64_t)b.bytes_capacity;
+
+  // the value before the page
+  uint32_t last_len = 0;
+  const uint8_t* last_ptr = nullptr;  // its bytes in global memory (for prefixes longer than `keep`)
+  if (b.prev_bytes && b.prev_offsets && b.prev_count) {
+    const int32_t p0 = b.prev_offsets[b.prev_count - 1], p1 = b.prev_offsets[b.prev_count];
+    last_len = p1 > p0 ? (uint32_t)(p1 - p0) : 0u;
+    last_ptr = b.prev_bytes + p0;
+    for (uint32_t t = lane; t < last_len && t < DB_KEEP; t += 64) keep[t] = last_ptr[t];
+  }
+
+  uint32_t i0 = 0;
+  uint64_t run_out = 0, run_in = 0;
+  int32_t status = PQD_OK;
+  while (i0 < n) {
+    const uint32_t idx = i0 + lane;
+    const bool valid = idx < n;
+    const int32_t P = valid ? prefix[idx] : 0, S = valid ? suffix[idx] : 0;
+    const bool negative = P < 0 || S < 0;
+    const uint32_t p = negative ? 0u : (uint32_t)P, s = negative ? 0u : (uint32_t)S;
+    const uint64_t len = (uint64_t)p + s;
+    const uint64_t len_before = shuffle_u32((uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len), (lane + 63u) & 63u);
+    const uint64_t prev_len = lane == 0 ? last_len : len_before;
+    const uint64_t so_inc = wave_scan_inclusive((uint64_t)s), oo_inc = wave_scan_inclusive(len);
+    const uint64_t so = so_inc - s, oo = oo_inc - len;
+    const bool broken = valid && (negative || p > prev_len || run_in + so_inc > savail);
+    const bool too_big = valid && run_out + oo_inc > cap;
+    const uint64_t fail_mask = __ballot(broken || too_big || !valid);
+    const uint32_t deliverable = fail_mask ? (uint32_t)__builtin_ctzll(fail_mask) : 64u;
+    if (deliverable == 0) {  // lane 0's value fails (it is valid: i0 < n)
+      status = __builtin_amdgcn_readfirstlane((int)broken) ? PQD_DECODE : PQD_BAD_ARG;
+      break;
+    }
+    // how many of them fit the tiles
+    const bool fits = oo_inc <= DB_OUT && so_inc <= DB_IN && p <= DB_KEEP;
+    const uint64_t unfit_mask = __ballot(!fits);
+    uint32_t m = unfit_mask ? (uint32_t)__builtin_ctzll(unfit_mask) : 64u;
+    m = m < deliverable ? m : deliverable;
+    uint8_t* dst = b.bytes + run_out;
+    if (m == 0) {
+      // one value through global memory: its prefix from where the value before it was written
+      const uint32_t p0 = __builtin_amdgcn_readfirstlane(p), s0 = __builtin_amdgcn_readfirstlane(s);
+      __threadfence();
+      for (uint32_t t = lane; t < p0; t += 64) dst[t] = load_written_byte(last_ptr + t);
+      const uint8_t* src = sdata + run_in;
+      for (uint32_t t = lane; t < s0; t += 64) {
+        const uint8_t v = src[t];
+        dst[p0 + t] = v;
+        if (p0 + t < DB_KEEP) keep[p0 + t] = v;
+      }
+      if (lane == 0) b.offsets[i0] = (int32_t)run_out;
+      last_ptr = dst;
+      last_len = p0 + s0;
+      run_out += (uint64_t)p0 + s0;
+      run_in += s0;
+      i0 += 1;
+      continue;
+    }
+    const uint32_t in_bytes = shuffle_u32((uint32_t)so_inc, m - 1);
+    const uint32_t out_bytes = shuffle_u32((uint32_t)oo_inc, m - 1);
+    const bool mine = lane < m;
+    // suffix bytes of the batch -> LDS
+    {
+      const uint8_t* src = sdata + run_in;
+      const uint64_t left = savail - run_in;  // bytes that exist behind src
+      for (uint32_t t = lane * 16u; t < in_bytes; t += 1024u) {
+        if ((uint64_t)t + 16u <= left) {
+          u32x4 v;
+          __builtin_memcpy(&v, src + t, 16);
+          *reinterpret_cast<u32x4*>(in_tile + t) = v;
+        } else {
+          for (uint32_t k = 0; t + k < in_bytes; ++k) in_tile[t + k] = src[t + k];
+        }
+      }
+    }
+    // the tile is laid out like the destination: byte x of the batch at out_tile[a + x]
+    const uint32_t a = (uint32_t)((uintptr_t)dst & 15u);
+    const uint32_t o = a + (uint32_t)oo;  // this lane's value in the tile
+    __syncthreads();  // (one wave: only an order for the LDS accesses)
+    // prefix columns
+    uint32_t longest = mine ? p : 0u;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+      const uint32_t other = shuffle_u32(longest, lane ^ (uint32_t)sh);
+      longest = other > longest ? other : longest;
+    }
+    longest = __builtin_amdgcn_readfirstlane(longest);
+    const uint32_t own_base = (uint32_t)so - p;  // in_tile index of this value's byte j is own_base + j (j >= p)
+    const uint64_t below = (2ull << lane) - 1ull;
+    for (uint32_t j = 0; j < longest; ++j) {
+      const uint64_t owners = __ballot(mine && p <= j) & below;
+      const uint32_t owner = owners ? 63u - (uint32_t)__builtin_clzll(owners) : 0u;
+      const uint32_t base = shuffle_u32(own_base, owner);
+      if (mine && j < p) {
+        const uint8_t v = owners ? in_tile[base + j] : keep[j];
+        out_tile[o + j] = v;
+        if (lane == m - 1) keep[j] = v;
+      }
+    }
+    // suffixes
+    {
+      uint32_t longest_s = mine ? s : 0u;
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) {
+        const uint32_t other = shuffle_u32(longest_s, lane ^ (uint32_t)sh);
+        longest_s = other > longest_s ? other : longest_s;
+      }
+      longest_s = __builtin_amdgcn_readfirstlane(longest_s);
+      if (longest_s <= 64u) {
+        for (uint32_t t = 0; t < longest_s; ++t) {
+          if (mine && t < s) {
+            const uint8_t v = in_tile[(uint32_t)so + t];
+            out_tile[o + p + t] = v;
+            if (lane == m - 1 && p + t < DB_KEEP) keep[p + t] = v;
+          }
+        }
+      } else {
+        for (uint32_t k = 0; k < m; ++k) {  // one value after the other, the lanes side by side
+          const uint32_t ks = shuffle_u32(s, k), kso = shuffle_u32((uint32_t)so, k), ko = shuffle_u32(o + p, k);
+          const uint32_t kp = shuffle_u32(p, k);
+          for (uint32_t t = lane; t < ks; t += 64) {
+            const uint8_t v = in_tile[kso + t];
+            out_tile[ko + t] = v;
+            if (k == m - 1 && kp + t < DB_KEEP) keep[kp + t] = v;
+          }
+        }
+      }
+    }
+    if (mine) b.offsets[idx] = (int32_t)(run_out + oo);
+    __syncthreads();
+    // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
+    {
+      uint8_t* gbase = dst - a;  // 16-byte aligned
+      const uint32_t end = a + out_bytes;
+      for (uint32_t t = lane * 16u; t < end; t += 1024u) {
+        if (t >= a && t + 16u <= end) {
+          *reinterpret_cast<u32x4*>(gbase + t) = *reinterpret_cast<const u32x4*>(out_tile + t);
+        } else {
+          for (uint32_t k = 0; k < 16u; ++k)
+            if (t + k >= a && t + k < end) gbase[t + k] = out_tile[t + k];
+        }
+      }
+    }
+    last_len = shuffle_u32((uint32_t)len, m - 1);
+    last_ptr = dst + shuffle_u32((uint32_t)oo, m - 1);
+    run_out += out_bytes;
+    run_in += in_bytes;
+    i0 += m;
+    __syncthreads();
+  }
+  if (status == PQD_OK && i0 < b.num_values) status = PQD_DECODE;  // "no more value to read" from a length block
+  if (lane == 0) {
+    b.offsets[i0] = (int32_t)run_out;
+    pqd_page_result r = {status, i0, lb.header + (uint32_t)run_in, (uint32_t)run_out};
+    results[page] = r;
+  }
+}
+
+hipError_t launch_delta_bytes(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_delta_length_bytes, dim3(n_pages), dim3(DL_THREADS), 0, stream, descs, results, n_pages);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_delta_byte_array, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

@@ -912,6 +912,89 @@ int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_resul
   return PQD_OK;
 }
 
+int pqd_delta_byte_array_dev(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  PQD_HIP(pqd::launch_delta_length_blocks(descs, n_pages, as_stream(stream)));
+  PQD_HIP(pqd::launch_delta_bytes(descs, results, n_pages, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t page_len, uint32_t num_values,
+                                     const uint8_t* previous, uint32_t previous_len, int32_t* offsets, uint8_t* bytes,
+                                     uint32_t bytes_capacity, pqd_page_result* result, uint64_t* bytes_needed) {
+  if (!result || !offsets) return fail(PQD_BAD_ARG, "null result / offsets");
+  if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY)
+    return fail(PQD_BAD_ARG, "not a delta byte array encoding");
+  if ((page_len && !page) || (bytes_capacity && !bytes) || (previous_len && !previous))
+    return fail(PQD_BAD_ARG, "null page / output / previous value");
+  int st = check_device_available();
+  if (st) return st;
+  HostCtx& c = g_ctx;
+  hipStream_t s;
+  if ((st = c.ensure_stream(&s))) return st;
+  const bool chained = encoding == PQD_ENC_DELTA_BYTE_ARRAY && previous_len != 0;
+  // device staging: page | previous value | its two offsets (in `in`), work area (in `out`),
+  // offsets + bytes (in `dict`), descriptor, result
+  const size_t page_padded = ((size_t)page_len + 15) & ~(size_t)15, prev_padded = ((size_t)previous_len + 15) & ~(size_t)15;
+  const size_t offs_padded = (((size_t)num_values + 1) * 4 + 15) & ~(size_t)15;
+  if ((st = c.in.ensure(page_padded + prev_padded + 32))) return st;
+  if ((st = c.out.ensure(PQD_DELTA_BYTES_WORK(num_values) + 16))) return st;
+  if ((st = c.descs.ensure(sizeof(pqd_delta_bytes_desc)))) return st;
+  if ((st = c.results.ensure(sizeof(pqd_page_result)))) return st;
+  uint8_t* d_in = (uint8_t*)c.in.p;
+  if (page_len) PQD_HIP(hipMemcpyAsync(d_in, page, page_len, hipMemcpyHostToDevice, s));
+  const int32_t prev_offsets[2] = {0, (int32_t)previous_len};
+  if (chained) {
+    PQD_HIP(hipMemcpyAsync(d_in + page_padded, previous, previous_len, hipMemcpyHostToDevice, s));
+    PQD_HIP(hipMemcpyAsync(d_in + page_padded + prev_padded, prev_offsets, sizeof prev_offsets, hipMemcpyHostToDevice, s));
+  }
+  pqd_delta_bytes_desc d{};
+  d.data = d_in;
+  d.work = (uint8_t*)c.out.p;
+  d.data_len = page_len;
+  d.num_values = num_values;
+  d.encoding = (uint32_t)encoding;
+  if (chained) {
+    d.prev_bytes = d_in + page_padded;
+    d.prev_offsets = (const int32_t*)(d_in + page_padded + prev_padded);
+    d.prev_count = 1;
+  }
+  // the length blocks first: their sum is the room the values need
+  PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
+  PQD_HIP(pqd::launch_delta_length_blocks((const pqd_delta_bytes_desc*)c.descs.p, 1, s));
+  const int blocks = encoding == PQD_ENC_DELTA_BYTE_ARRAY ? 2 : 1;
+  std::vector<int32_t> lengths((size_t)num_values * blocks);
+  pqd_page_result block_result[2] = {};
+  PQD_HIP(hipMemcpyAsync(block_result, c.out.p, sizeof block_result, hipMemcpyDeviceToHost, s));
+  if (!lengths.empty())
+    PQD_HIP(hipMemcpyAsync(lengths.data(), (uint8_t*)c.out.p + 64, lengths.size() * 4, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  uint64_t need = 0;
+  for (int b = 0; b < blocks; ++b) {
+    if (block_result[b].status != PQD_OK) break;  // the page fails before its first value
+    const uint32_t have = block_result[b].values_written < num_values ? block_result[b].values_written : num_values;
+    for (uint32_t i = 0; i < have; ++i) {
+      const int32_t v = lengths[(size_t)b * num_values + i];
+      need += v > 0 ? (uint64_t)v : 0u;
+    }
+  }
+  if (bytes_needed) *bytes_needed = need;
+  const uint64_t room = need < bytes_capacity ? need : bytes_capacity;
+  if ((st = c.dict.ensure(offs_padded + room + 32))) return st;
+  d.offsets = (int32_t*)c.dict.p;
+  d.bytes = (uint8_t*)c.dict.p + offs_padded;
+  d.bytes_capacity = (uint32_t)room;
+  PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
+  PQD_HIP(pqd::launch_delta_bytes((const pqd_delta_bytes_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, s));
+  PQD_HIP(hipMemcpyAsync(result, c.results.p, sizeof *result, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  PQD_HIP(hipMemcpyAsync(offsets, d.offsets, ((size_t)result->values_written + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (result->reserved) PQD_HIP(hipMemcpyAsync(bytes, d.bytes, result->reserved, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  return PQD_OK;
+}
+
 int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                            int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result) {
   if (!dict || !result) return fail(PQD_BAD_ARG, "null dictionary handle / result");

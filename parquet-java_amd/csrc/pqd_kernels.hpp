@@ -37,6 +37,11 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
                                     uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream);
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream);
+// DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: the length blocks into the page's work area (two result
+// records in DELTA_BYTES_WORK_HEADER bytes, then the int32 lengths), then offsets + bytes
+constexpr uint32_t DELTA_BYTES_WORK_HEADER = 64;
+hipError_t launch_delta_length_blocks(const pqd_delta_bytes_desc* descs, uint32_t n_pages, hipStream_t stream);
+hipError_t launch_delta_bytes(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_bss_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                             hipStream_t stream);
 hipError_t launch_bitpacked_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
