@@ -516,6 +516,53 @@ int pqd_chunk_sections_dev(const pqd_chunk_page* sections, uint32_t n_pages, con
 int pqd_chunk_set_value_counts_dev(pqd_page_desc* val_descs, const pqd_page_result* validity_results, uint32_t n_pages,
                                    void* stream);
 
+/* ---- page decompression --------------------------------------------------------------------------- */
+/*
+ * Replaces BytesInputDecompressor.decompress(bytes, uncompressedSize) as ColumnChunkPageReadStore calls it
+ * for every page (parquet-hadoop/.../hadoop/ColumnChunkPageReadStore.java:151-181 V1 and dictionary pages,
+ * :232-262 V2 where only the values behind the level bytes are compressed; CodecFactory.java:176-210), on
+ * the DEVICE and for many pages per call.  Codecs (numbered as parquet-format's CompressionCodec, which
+ * CompressionCodecName.java:26-33 mirrors): SNAPPY = the raw Snappy format (SnappyDecompressor.java:27-35
+ * -> org.xerial.snappy.Snappy.uncompress), LZ4_RAW = the LZ4 block format (Lz4RawDecompressor.java:29-49
+ * -> io.airlift.compress.lz4.Lz4Decompressor), UNCOMPRESSED = a copy.  A page must produce exactly dst_len
+ * bytes (the reference reads uncompressed_page_size bytes from the codec's stream): PQD_DECODE for a
+ * malformed stream, one that would write past dst_len, or one that ends short of it ("could not
+ * decompress page"); result.values_written = bytes produced, bytes_consumed = source bytes read.
+ * desc.codec is the call's `codec` or PQD_CODEC_UNCOMPRESSED (stored parts of the same batch).
+ */
+enum pqd_codec {
+  PQD_CODEC_UNCOMPRESSED = 0, PQD_CODEC_SNAPPY = 1, PQD_CODEC_GZIP = 2, PQD_CODEC_LZO = 3, PQD_CODEC_BROTLI = 4,
+  PQD_CODEC_LZ4 = 5, PQD_CODEC_ZSTD = 6, PQD_CODEC_LZ4_RAW = 7
+};
+typedef struct pqd_decompress_desc {
+  const uint8_t* src; /* DEVICE: compressed bytes                                                          */
+  uint8_t* dst;       /* DEVICE: dst_len bytes                                                             */
+  uint32_t src_len;   /* below 2^31                                                                        */
+  uint32_t dst_len;   /* the uncompressed size the page header announces                                   */
+  uint32_t codec;     /* enum pqd_codec                                                                    */
+  uint32_t reserved;
+} pqd_decompress_desc;
+int pqd_decompress_pages_dev(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
+                             void* stream);
+/* Whether pqd_decompress_pages_dev handles `codec` (SNAPPY, LZ4_RAW, UNCOMPRESSED). */
+int pqd_codec_supported(int codec);
+/*
+ * All pages of a walked chunk: `pages` is the HOST table of pqd_chunk_walk, `chunk` the chunk's bytes on
+ * the DEVICE.  Every page body is laid out uncompressed in `bodies` (DEVICE, bodies_capacity bytes; the
+ * sum of the uncompressed sizes, each rounded up to 16, is enough), V2 level bytes copied as they are.
+ * uncompressed_pages (HOST, n_pages entries) receives the same table with body_offset = the page's place
+ * in `bodies`, compressed_size = uncompressed_size and is_compressed = 0: the table
+ * pqd_chunk_sections_dev and pqd_dict_create take.  descs / results: DEVICE scratch of 2 * n_pages
+ * entries each; results[2 * i] and results[2 * i + 1] are page i's (a page has at most two parts).
+ * PQD_BAD_ARG: unsupported codec, bodies too small.
+ */
+int pqd_chunk_decompress_dev(const uint8_t* chunk, const pqd_chunk_page* pages, uint32_t n_pages, int codec,
+                             uint8_t* bodies, size_t bodies_capacity, pqd_chunk_page* uncompressed_pages,
+                             pqd_decompress_desc* descs, pqd_page_result* results, void* stream);
+/* One page body in HOST memory -> dst_len bytes in HOST memory.  Thread-safe like the other host entries. */
+int pqd_decompress_page(int codec, const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len,
+                        pqd_page_result* result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,8 @@ def _declare(L):
     L.orc_def_validity.restype = None
     L.orc_scatter_nulls.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, _u8p, _szp, _szp]
     L.orc_rep_offsets.argtypes = [_i32p, _i32p, C.c_size_t, C.c_int32, C.c_int32, C.c_size_t, _i32p, _u8p, _szp, _szp]
+    L.orc_snappy_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
+    L.orc_lz4_raw_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
     L.orc_delta_length_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp, _szp]
     L.orc_delta_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp,
                                        _szp]
@@ -348,3 +350,14 @@ def delta_byte_array(data, n, cap, prev=b""):
     st = lib().orc_delta_byte_array(_p(data, _u8p), data.size, n, _p(pv, _u8p), prev.size, _p(offsets, _i32p), _p(out, _u8p),
                                     cap, C.byref(wr), C.byref(used), C.byref(nb))
     return st, offsets[:wr.value + 1], out[:nb.value], used.value
+
+
+# ---------------------------------------------------------------- page decompression
+def decompress(codec, data, size):
+    """(status, bytes produced, consumed) of a SNAPPY / LZ4_RAW page body that should hold `size` bytes."""
+    data = _u8(data)
+    out = np.zeros(max(size, 1), np.uint8)
+    made, used = C.c_size_t(0), C.c_size_t(0)
+    f = {"SNAPPY": lib().orc_snappy_decompress, "LZ4_RAW": lib().orc_lz4_raw_decompress}[codec]
+    st = f(_p(data, _u8p), data.size, _p(out, _u8p), size, C.byref(made), C.byref(used))
+    return st, out[:made.value], used.value

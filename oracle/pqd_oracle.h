@@ -112,6 +112,13 @@ int orc_delta_byte_array(const uint8_t* in, size_t in_len, size_t n, const uint8
                          int32_t* offsets, uint8_t* bytes, size_t cap, size_t* written, size_t* consumed,
                          size_t* bytes_written);
 
+/* ---- page decompression (pqd_oracle_pages.c): raw Snappy and LZ4 block format; `cap` = the page header's
+ * uncompressed size, which the stream must produce exactly */
+int orc_snappy_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced,
+                          size_t* consumed);
+int orc_lz4_raw_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced,
+                           size_t* consumed);
+
 /* ---- BytesUtils helpers (parquet-common BytesUtils.java:202-269), exposed for tests */
 int orc_read_uvarint32(const uint8_t* in, size_t len, size_t* pos, uint32_t* v);
 int orc_read_zigzag_varlong(const uint8_t* in, size_t len, size_t* pos, int64_t* v);

@@ -237,3 +237,171 @@ int orc_delta_byte_array(const uint8_t* in, size_t in_len, size_t n, const uint8
   *bytes_written = out;
   return st;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Page decompression: SNAPPY and LZ4_RAW                                      */
+/* ------------------------------------------------------------------------- */
+/* The reference hands a page body to a codec of a third-party library and expects exactly
+ * uncompressed_page_size bytes back (ColumnChunkPageReadStore.java:151-181,232-262, CodecFactory.java:
+ * 176-195: BytesInput.from(stream, decompressedSize); any failure is "could not decompress page").
+ * SNAPPY: SnappyDecompressor.java:27-35 calls org.xerial.snappy.Snappy.uncompress (snappy-java 1.1.10.8,
+ * parquet-hadoop/pom.xml:145-147), the raw Snappy format: a varint32 with the uncompressed length, then
+ * elements tagged by their low two bits - 00 literal (length-1 in the upper six bits, or 60..63 = that
+ * many minus 59 little-endian length bytes), 01 copy of 4..11 bytes with an 11-bit offset, 10 copy of
+ * 1..64 bytes with a 16-bit offset, 11 copy of 1..64 bytes with a 32-bit offset; copies may overlap
+ * their own output.  LZ4_RAW: Lz4RawDecompressor.java:29-49 calls io.airlift.compress.lz4.Lz4Decompressor
+ * (aircompressor 2.0.3, parquet-hadoop/pom.xml:157-161), the LZ4 block format: sequences of a token
+ * (literal length in the high nibble, match length - 4 in the low one, 15 = add the following bytes up
+ * to and including the first that is not 255), the literals, a 16-bit little-endian offset (0 is
+ * invalid) and the match; the last sequence ends after its literals.
+ * Neither library is in the reference tree: the restatement follows the published formats and is pinned
+ * by pages compressed with the C libraries of the same formats (through pyarrow). */
+
+#define ORC_CODEC_SNAPPY 1
+#define ORC_CODEC_LZ4_RAW 2
+
+static int lz_copy_match(uint8_t* out, size_t* op, size_t cap, size_t offset, size_t len) {
+  if (offset == 0 || offset > *op || len > cap - *op) return ORC_DECODE;
+  for (size_t i = 0; i < len; ++i) out[*op + i] = out[*op - offset + i]; /* byte by byte: overlaps repeat */
+  *op += len;
+  return ORC_OK;
+}
+
+int orc_snappy_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced,
+                          size_t* consumed) {
+  size_t ip = 0, op = 0;
+  *produced = *consumed = 0;
+  /* preamble: varint32 */
+  uint64_t ulen = 0;
+  int shift = 0, ok = 0;
+  while (ip < in_len && shift <= 28) {
+    uint8_t b = in[ip++];
+    ulen |= (uint64_t)(b & 0x7F) << shift;
+    if (!(b & 0x80)) {
+      ok = 1;
+      break;
+    }
+    shift += 7;
+  }
+  if (!ok || ulen > 0xFFFFFFFFull) return ORC_DECODE;
+  int st = ORC_OK;
+  while (ip < in_len) {
+    uint8_t tag = in[ip];
+    size_t hdr, len, offset = 0;
+    switch (tag & 3) {
+      case 0: {
+        size_t l = tag >> 2;
+        hdr = 1;
+        if (l >= 60) {
+          size_t nb = l - 59;
+          if (in_len - ip < 1 + nb) {
+            st = ORC_DECODE;
+            goto done;
+          }
+          l = 0;
+          for (size_t k = 0; k < nb; ++k) l |= (size_t)in[ip + 1 + k] << (8 * k);
+          hdr = 1 + nb;
+        }
+        len = l + 1;
+        if (len > in_len - ip - hdr || len > cap - op) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        memcpy(out + op, in + ip + hdr, len);
+        op += len;
+        ip += hdr + len;
+        continue;
+      }
+      case 1:
+        hdr = 2;
+        if (in_len - ip < hdr) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        len = 4 + ((tag >> 2) & 7);
+        offset = ((size_t)(tag >> 5) << 8) | in[ip + 1];
+        break;
+      case 2:
+        hdr = 3;
+        if (in_len - ip < hdr) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        len = 1 + (tag >> 2);
+        offset = (size_t)in[ip + 1] | ((size_t)in[ip + 2] << 8);
+        break;
+      default:
+        hdr = 5;
+        if (in_len - ip < hdr) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        len = 1 + (tag >> 2);
+        offset = (size_t)in[ip + 1] | ((size_t)in[ip + 2] << 8) | ((size_t)in[ip + 3] << 16) | ((size_t)in[ip + 4] << 24);
+        break;
+    }
+    if ((st = lz_copy_match(out, &op, cap, offset, len))) goto done;
+    ip += hdr;
+  }
+  /* the stream must produce what its preamble announced, and the page what its header announced */
+  if (op != ulen || op != cap) st = ORC_DECODE;
+done:
+  *produced = op;
+  *consumed = ip;
+  return st;
+}
+
+int orc_lz4_raw_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced,
+                           size_t* consumed) {
+  size_t ip = 0, op = 0;
+  int st = ORC_OK;
+  *produced = *consumed = 0;
+  while (ip < in_len) {
+    uint8_t token = in[ip++];
+    size_t lit = token >> 4;
+    if (lit == 15) {
+      uint8_t b;
+      do {
+        if (ip >= in_len) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        b = in[ip++];
+        lit += b;
+      } while (b == 255);
+    }
+    if (lit > in_len - ip || lit > cap - op) {
+      st = ORC_DECODE;
+      goto done;
+    }
+    memcpy(out + op, in + ip, lit);
+    op += lit;
+    ip += lit;
+    if (ip == in_len) break; /* the last sequence has no match */
+    if (in_len - ip < 2) {
+      st = ORC_DECODE;
+      goto done;
+    }
+    size_t offset = (size_t)in[ip] | ((size_t)in[ip + 1] << 8);
+    ip += 2;
+    size_t mlen = token & 15;
+    if (mlen == 15) {
+      uint8_t b;
+      do {
+        if (ip >= in_len) {
+          st = ORC_DECODE;
+          goto done;
+        }
+        b = in[ip++];
+        mlen += b;
+      } while (b == 255);
+    }
+    mlen += 4;
+    if ((st = lz_copy_match(out, &op, cap, offset, mlen))) goto done;
+  }
+  if (op != cap) st = ORC_DECODE; /* the page header announced cap bytes */
+done:
+  *produced = op;
+  *consumed = ip;
+  return st;
+}

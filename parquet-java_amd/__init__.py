@@ -16,14 +16,14 @@ import ctypes as _C
 import numpy as _np
 
 from . import _native
-from ._native import (BAD_ARG, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
+from ._native import (BAD_ARG, CODEC_LZ4_RAW, CODEC_SNAPPY, CODEC_UNCOMPRESSED, CODEC_ZSTD, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
                       ENC_DELTA_BINARY_PACKED, ENC_DELTA_BYTE_ARRAY, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
                       HIP_ERROR, NO_DEVICE, OK, PAGE_DATA, PAGE_DATA_V2, PAGE_DICTIONARY, PAGE_INDEX, PAST_END, TYPE_BOOLEAN, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
-                      BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DeltaBytesDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
+                      BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DecompressDesc, DeltaBytesDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
-           "DictionaryValuesReader", "PlainBinaryDictionary", "DeltaBinaryPackingValuesReader", "DeltaLengthByteArrayValuesReader", "DeltaByteArrayReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
+           "DictionaryValuesReader", "PlainBinaryDictionary", "BytesDecompressor", "DeltaBinaryPackingValuesReader", "DeltaLengthByteArrayValuesReader", "DeltaByteArrayReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
 
@@ -721,6 +721,31 @@ class BooleanPlainValuesReader(ValuesReader):
 
     def skip(self, n=1):
         self._i += n  # the reference only moves its bit index; a later read fails
+
+
+class BytesDecompressor:
+    """CodecFactory.BytesDecompressor (parquet-hadoop/.../hadoop/CodecFactory.java:165-217) for the codecs
+    the device handles: ``decompress(bytes, decompressedSize)`` returns exactly ``decompressedSize``
+    bytes or raises IOError, which ColumnChunkPageReadStore turns into "could not decompress page"."""
+    _codecs = {"UNCOMPRESSED": CODEC_UNCOMPRESSED, "SNAPPY": CODEC_SNAPPY, "LZ4_RAW": CODEC_LZ4_RAW, "ZSTD": CODEC_ZSTD}
+
+    def __init__(self, codecName):
+        if codecName not in self._codecs or not lib.pqd_codec_supported(self._codecs[codecName]):
+            raise IllegalArgumentException("no device decompressor for " + str(codecName))
+        self._codec = self._codecs[codecName]
+
+    def decompress(self, data, decompressedSize):
+        src = _np.frombuffer(bytes(data), _np.uint8)
+        dst = _np.zeros(max(decompressedSize, 1), _np.uint8)
+        r = PageResult()
+        check(lib.pqd_decompress_page(self._codec, _ptr(src) if src.size else None, src.size, _ptr(dst), decompressedSize,
+                                      _C.byref(r)), "pqd_decompress_page")
+        if r.status != OK:
+            raise IOError("could not decompress page: %d of %d bytes" % (r.values_written, decompressedSize))
+        return dst[:decompressedSize].tobytes()
+
+    def release(self):
+        pass
 
 
 def make_descs(pages):

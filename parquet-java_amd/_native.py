@@ -23,6 +23,7 @@ F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
 TYPE_BOOLEAN, TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 0, 1, 2, 3, 4, 5, 6, 7
 PAGE_DATA, PAGE_INDEX, PAGE_DICTIONARY, PAGE_DATA_V2 = 0, 1, 2, 3
 VIEW_INVALID = 0xFFFFFFFFFFFFFFFF
+CODEC_UNCOMPRESSED, CODEC_SNAPPY, CODEC_GZIP, CODEC_LZO, CODEC_BROTLI, CODEC_LZ4, CODEC_ZSTD, CODEC_LZ4_RAW = range(8)
 
 
 class PageDesc(C.Structure):
@@ -72,6 +73,11 @@ class DeltaBytesDesc(C.Structure):
 def delta_bytes_work(num_values):
     """PQD_DELTA_BYTES_WORK: bytes of scratch a delta byte array page needs."""
     return 64 + 8 * num_values
+
+
+class DecompressDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_len", C.c_uint32), ("dst_len", C.c_uint32),
+                ("codec", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ChunkPage(C.Structure):
@@ -148,6 +154,11 @@ EXPORTS = {
     "pqd_delta_byte_array_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_decode_delta_byte_array_page": ([C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_uint32, C.POINTER(PageResult), C.POINTER(C.c_uint64)], C.c_int),
+    "pqd_decompress_pages_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
+    "pqd_codec_supported": ([C.c_int], C.c_int),
+    "pqd_chunk_decompress_dev": ([C.c_void_p, C.POINTER(ChunkPage), C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+                                  C.POINTER(ChunkPage), C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "pqd_decompress_page": ([C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(PageResult)], C.c_int),
     "pqd_decode_binary_page": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.POINTER(PageResult)], C.c_int),
 }

@@ -995,6 +995,90 @@ int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t
   return PQD_OK;
 }
 
+int pqd_codec_supported(int codec) {
+  return codec == PQD_CODEC_UNCOMPRESSED || codec == PQD_CODEC_SNAPPY || codec == PQD_CODEC_LZ4_RAW;
+}
+
+int pqd_decompress_pages_dev(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
+                             void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  PQD_HIP(pqd::launch_decompress_pages(descs, results, n_pages, codec, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_chunk_decompress_dev(const uint8_t* chunk, const pqd_chunk_page* pages, uint32_t n_pages, int codec,
+                             uint8_t* bodies, size_t bodies_capacity, pqd_chunk_page* uncompressed_pages,
+                             pqd_decompress_desc* descs, pqd_page_result* results, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!chunk || !pages || !bodies || !uncompressed_pages || !descs || !results)
+    return fail(PQD_BAD_ARG, "null chunk / page table / output");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  static thread_local std::vector<pqd_decompress_desc> host;
+  host.assign((size_t)n_pages * 2, pqd_decompress_desc{});
+  size_t at = 0;
+  for (uint32_t i = 0; i < n_pages; ++i) {
+    const pqd_chunk_page& p = pages[i];
+    pqd_chunk_page& u = uncompressed_pages[i];
+    u = p;
+    const size_t room = ((size_t)p.uncompressed_size + 15) & ~(size_t)15;
+    if (at + room > bodies_capacity || at > 0xFFFFFFFFull) return fail(PQD_BAD_ARG, "bodies_capacity too small");
+    u.body_offset = (uint32_t)at;
+    u.compressed_size = p.uncompressed_size;
+    u.is_compressed = 0;
+    // V2: the level bytes are stored as they are, only the values behind them are compressed (:232-262)
+    uint32_t levels = p.type == PQD_PAGE_DATA_V2 ? p.rep_levels_len + p.def_levels_len : 0u;
+    if (levels > p.compressed_size || levels > p.uncompressed_size) return fail(PQD_DECODE, "level bytes beyond the page");
+    pqd_decompress_desc& a = host[2 * (size_t)i];
+    pqd_decompress_desc& b = host[2 * (size_t)i + 1];
+    a.src = chunk + p.body_offset;
+    a.dst = bodies + at;
+    a.src_len = a.dst_len = levels;
+    a.codec = PQD_CODEC_UNCOMPRESSED;
+    b.src = chunk + p.body_offset + levels;
+    b.dst = bodies + at + levels;
+    b.src_len = p.compressed_size - levels;
+    b.dst_len = p.uncompressed_size - levels;
+    b.codec = (p.type == PQD_PAGE_DATA_V2 && !p.is_compressed) ? (uint32_t)PQD_CODEC_UNCOMPRESSED : (uint32_t)codec;
+    at += room;
+  }
+  hipStream_t s = as_stream(stream);
+  PQD_HIP(hipMemcpyAsync(descs, host.data(), host.size() * sizeof(pqd_decompress_desc), hipMemcpyHostToDevice, s));
+  PQD_HIP(pqd::launch_decompress_pages(descs, results, 2 * n_pages, codec, s));
+  return PQD_OK;
+}
+
+int pqd_decompress_page(int codec, const uint8_t* src, uint32_t src_len, uint8_t* dst, uint32_t dst_len,
+                        pqd_page_result* result) {
+  if (!result) return fail(PQD_BAD_ARG, "null result");
+  if ((src_len && !src) || (dst_len && !dst)) return fail(PQD_BAD_ARG, "null source / destination");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  int st = check_device_available();
+  if (st) return st;
+  HostCtx& c = g_ctx;
+  hipStream_t s;
+  if ((st = c.ensure_stream(&s))) return st;
+  if ((st = c.in.ensure((size_t)src_len + 16))) return st;
+  if ((st = c.out.ensure((size_t)dst_len + 16))) return st;
+  if ((st = c.descs.ensure(sizeof(pqd_decompress_desc)))) return st;
+  if ((st = c.results.ensure(sizeof(pqd_page_result)))) return st;
+  if (src_len) PQD_HIP(hipMemcpyAsync(c.in.p, src, src_len, hipMemcpyHostToDevice, s));
+  pqd_decompress_desc d{};
+  d.src = (const uint8_t*)c.in.p;
+  d.dst = (uint8_t*)c.out.p;
+  d.src_len = src_len;
+  d.dst_len = dst_len;
+  d.codec = (uint32_t)codec;
+  PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
+  PQD_HIP(pqd::launch_decompress_pages((const pqd_decompress_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, codec, s));
+  PQD_HIP(hipMemcpyAsync(result, c.results.p, sizeof *result, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  if (result->values_written) PQD_HIP(hipMemcpyAsync(dst, c.out.p, result->values_written, hipMemcpyDeviceToHost, s));
+  PQD_HIP(hipStreamSynchronize(s));
+  return PQD_OK;
+}
+
 int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                            int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result) {
   if (!dict || !result) return fail(PQD_BAD_ARG, "null dictionary handle / result");

@@ -97,7 +97,8 @@ def test_walk_failures():
 
 # ------------------------------------------------------------------------------- whole chunks on the device
 PHYS = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
-WHOLE = [fx for fx in ARROW if fx["codec"] == "UNCOMPRESSED" and fx["max_rep"] == 0 and
+CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "LZ4": 7}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
+WHOLE = [fx for fx in ARROW if fx["codec"] in CODECS and fx["max_rep"] == 0 and
          fx["physical_type"] in ("INT32", "INT64", "FLOAT", "DOUBLE", "BOOLEAN", "FIXED_LEN_BYTE_ARRAY") and
          not ({"DELTA_LENGTH_BYTE_ARRAY", "DELTA_BYTE_ARRAY"} & set(fx["encodings"]))]
 
@@ -116,12 +117,26 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     assert st == 0
     d_chunk = gh.to_dev(np.concatenate([np.frombuffer(chunk, np.uint8), np.zeros(64, np.uint8)]))
     elem = {"INT32": 4, "INT64": 8, "FLOAT": 4, "DOUBLE": 8, "BOOLEAN": 1, "FIXED_LEN_BYTE_ARRAY": fx["type_length"]}[fx["physical_type"]]
+    d_bodies = d_chunk
+    if CODECS[fx["codec"]]:
+        # compressed pages: every body is decompressed on the device into one buffer, which then is the chunk
+        cap = sum((p.uncompressed_size + 15) & ~15 for p in pages) + 64
+        d_bodies = torch.full((cap,), 0xA5, dtype=torch.uint8, device=gh.dev())
+        table_in, table_out = (pq.ChunkPage * len(pages))(*pages), (pq.ChunkPage * len(pages))()
+        d_cd = torch.zeros(2 * len(pages) * 32, dtype=torch.uint8, device=gh.dev())
+        d_cr = torch.zeros(2 * len(pages) * 16, dtype=torch.uint8, device=gh.dev())
+        pq.check(pq.lib.pqd_chunk_decompress_dev(d_chunk.data_ptr(), table_in, len(pages), CODECS[fx["codec"]], d_bodies.data_ptr(),
+                                                 cap - 64, table_out, d_cd.data_ptr(), d_cr.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert (pq.results_from_numpy(d_cr.cpu().numpy())[0] == 0).all()
+        pages = list(table_out)
+        assert all(p.is_compressed == 0 and p.compressed_size == p.uncompressed_size for p in pages)
     dict_page = [p for p in pages if p.type == pq.PAGE_DICTIONARY]
     data_pages = [p for p in pages if p.type != pq.PAGE_DICTIONARY]
     d_dict, dict_len = None, 0
     if dict_page:
         p = dict_page[0]
-        body = np.frombuffer(chunk, np.uint8)[p.body_offset:p.body_offset + p.compressed_size]
+        body = d_bodies.cpu().numpy()[p.body_offset:p.body_offset + p.compressed_size]
         d_dict = gh.to_dev(np.concatenate([body, np.zeros(16, np.uint8)]))  # PLAIN fixed-width dictionary page = the entries
         dict_len = p.num_values
     table = (pq.ChunkPage * len(data_pages))(*data_pages)
@@ -134,7 +149,7 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     out_elem = 4 if (fx["physical_type"] == "BOOLEAN" and "RLE" in fx["encodings"] and fx["data_page_version"] == "2.0") else elem
     d_val = torch.zeros(max(total, 1) * max(out_elem, elem) + 64, dtype=torch.uint8, device=gh.dev())
     meta = pq.ColumnMeta(PHYS[fx["physical_type"]], fx["type_length"], fx["max_def"], 0)
-    outs = pq.ChunkOutputs(d_chunk.data_ptr(), 0, d_def.data_ptr(), d_val.data_ptr(), d_base.data_ptr(), d_base.data_ptr(),
+    outs = pq.ChunkOutputs(d_bodies.data_ptr(), 0, d_def.data_ptr(), d_val.data_ptr(), d_base.data_ptr(), d_base.data_ptr(),
                            0 if d_dict is None else d_dict.data_ptr(), dict_len, 0)
     descs = [torch.zeros(n_pages * 40, dtype=torch.uint8, device=gh.dev()) for _ in range(3)]
     res = [torch.zeros(n_pages * 16, dtype=torch.uint8, device=gh.dev()) for _ in range(4)]

@@ -1,0 +1,298 @@
+"""Page decompression (SNAPPY, LZ4_RAW).  The algorithms live in third-party libraries the reference calls
+(snappy-java 1.1.10.8, aircompressor 2.0.3); the oracle restates the published formats (oracle/
+pqd_oracle_pages.c) and is pinned by byte strings and parquet pages compressed with the C libraries of the
+same formats through pyarrow (tests/golden/codec_vectors.json, pyarrow_chunks.json) and by hand-made streams
+that use every element type; the HIP kernels are checked against the oracle on all of these and on damaged
+streams."""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import codec_inputs
+import pagefile as pf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "codec_vectors.json")) as f:
+    VECTORS = [v for v in json.load(f)["vectors"] if v["codec"] in ("SNAPPY", "LZ4_RAW")]
+ORIGINALS = dict(codec_inputs.inputs())
+CODEC_NUM = {"SNAPPY": 1, "LZ4_RAW": 7, "UNCOMPRESSED": 0}
+PAGES = [fx for fx in pf.load_fixtures() if fx["codec"] in ("SNAPPY", "LZ4")]
+
+
+def compressed_parts(fx):
+    """[(compressed bytes, uncompressed size)] of the compressed parts of a chunk's pages."""
+    out = []
+    for page in pf.walk_chunk(pf.fixture_chunk(fx)):
+        body, size = page.body, page.uncompressed_size
+        if page.type == pf.DATA_PAGE_V2:
+            if not page.is_compressed:
+                continue
+            levels = page.rep_len + page.def_len
+            body, size = body[levels:], size - levels
+        out.append((body, size))
+    return out
+
+
+def varint(n):
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7F) | 0x80)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def handmade_snappy():
+    """(stream, original): every element type of the format description."""
+    rng = np.random.default_rng(5)
+    lit = lambda b: (bytes([(len(b) - 1) << 2]) if len(b) <= 60 else  # noqa: E731
+                     bytes([60 << 2, len(b) - 1]) if len(b) <= 256 else
+                     bytes([61 << 2]) + (len(b) - 1).to_bytes(2, "little") if len(b) <= 65536 else
+                     bytes([62 << 2]) + (len(b) - 1).to_bytes(3, "little")) + b
+    parts, out = [], bytearray()
+
+    def add_lit(b):
+        parts.append(lit(b))
+        out.extend(b)
+
+    def add_copy(offset, length, kind):
+        if kind == 1:
+            assert 4 <= length <= 11 and offset < 2048
+            parts.append(bytes([1 | ((length - 4) << 2) | ((offset >> 8) << 5), offset & 0xFF]))
+        elif kind == 2:
+            parts.append(bytes([2 | ((length - 1) << 2)]) + offset.to_bytes(2, "little"))
+        else:
+            parts.append(bytes([3 | ((length - 1) << 2)]) + offset.to_bytes(4, "little"))
+        for _ in range(length):
+            out.append(out[-offset])
+
+    add_lit(b"abcdefgh")
+    add_copy(8, 8, 1)
+    add_copy(1, 11, 1)      # a run
+    add_copy(3, 64, 2)      # overlapping, period 3
+    add_lit(bytes(rng.integers(0, 256, 61, dtype=np.uint8)))    # one length byte
+    add_lit(bytes(rng.integers(0, 256, 300, dtype=np.uint8)))   # two length bytes
+    add_lit(bytes(rng.integers(0, 256, 70000, dtype=np.uint8)))  # three length bytes
+    add_copy(70000, 64, 3)  # four-byte offset, beyond 64 KiB
+    add_copy(40000, 33, 2)  # beyond the 32 KiB the kernel keeps in LDS
+    add_copy(65, 64, 2)
+    add_copy(64, 64, 2)
+    add_copy(63, 64, 2)
+    add_lit(b"z")
+    return varint(len(out)) + b"".join(parts), bytes(out)
+
+
+def handmade_lz4():
+    rng = np.random.default_rng(6)
+    parts, out = [], bytearray()
+
+    def ext(n):
+        b = bytearray()
+        while n >= 255:
+            b.append(255)
+            n -= 255
+        b.append(n)
+        return bytes(b)
+
+    def seq(literals, offset=None, mlen=None):
+        ll = len(literals)
+        ml = 0 if offset is None else mlen - 4
+        token = (min(ll, 15) << 4) | min(ml, 15)
+        s = bytes([token]) + (ext(ll - 15) if ll >= 15 else b"") + literals
+        out.extend(literals)
+        if offset is not None:
+            s += offset.to_bytes(2, "little") + (ext(ml - 15) if ml >= 15 else b"")
+            for _ in range(mlen):
+                out.append(out[-offset])
+        parts.append(s)
+
+    seq(b"abcd", 4, 4)
+    seq(b"", 1, 300)           # a run with extension bytes
+    seq(bytes(rng.integers(0, 256, 15, dtype=np.uint8)), 3, 19)      # lengths exactly at the nibble limit
+    seq(bytes(rng.integers(0, 256, 15 + 255, dtype=np.uint8)), 7, 19 + 255)  # an extension byte of 255 then 0
+    seq(bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), 5000, 70000)  # longer than the kernel's ring
+    seq(bytes(rng.integers(0, 256, 40000, dtype=np.uint8)), 65535, 10)
+    seq(b"", 33000, 100)
+    seq(b"tail!")
+    return b"".join(parts), bytes(out)
+
+
+# ------------------------------------------------------------------------------- oracle
+def test_codec_inputs_are_the_ones_that_were_compressed():
+    for v in VECTORS:
+        raw = ORIGINALS[v["name"]]
+        assert len(raw) == v["size"] and hashlib.sha256(raw).hexdigest() == v["sha256"], v["name"]
+
+
+@pytest.mark.parametrize("v", VECTORS, ids=lambda v: v["codec"] + "." + v["name"])
+def test_oracle_decompresses_library_streams(orc, v):
+    st, out, used = orc.decompress(v["codec"], base64.b64decode(v["compressed"]), v["size"])
+    assert st == 0 and used == len(base64.b64decode(v["compressed"])) and bytes(out) == ORIGINALS[v["name"]]
+    # the page header's size has to be what the stream holds
+    for wrong in (v["size"] + 1, max(v["size"] - 1, 0)):
+        if wrong != v["size"]:
+            assert orc.decompress(v["codec"], base64.b64decode(v["compressed"]), wrong)[0] == orc.DECODE
+
+
+@pytest.mark.parametrize("fx", PAGES, ids=lambda fx: fx["file"] + "." + fx["column"])
+def test_oracle_decompresses_pyarrow_pages(orc, fx):
+    import pyarrow as pa
+    codec = "SNAPPY" if fx["codec"] == "SNAPPY" else "LZ4_RAW"
+    for body, size in compressed_parts(fx):
+        st, out, used = orc.decompress(codec, body, size)
+        assert st == 0 and used == len(body)
+        assert bytes(out) == (pa.Codec(codec.lower()).decompress(body, size, asbytes=True) if body else b"")
+
+
+def test_oracle_handmade_streams(orc):
+    for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("LZ4_RAW", handmade_lz4())):
+        st, out, used = orc.decompress(codec, stream, len(raw))
+        assert st == 0 and bytes(out) == raw and used == len(stream)
+        import pyarrow as pa
+        assert pa.Codec(codec.lower()).decompress(stream, len(raw), asbytes=True) == raw  # the C library reads them alike
+    # broken streams
+    D = orc.DECODE
+    assert orc.decompress("SNAPPY", b"", 0)[0] == D                       # no preamble
+    assert orc.decompress("SNAPPY", b"\x00", 0)[0] == 0                    # an empty page
+    assert orc.decompress("SNAPPY", b"\x05\x10abcde", 5)[0] == 0
+    assert orc.decompress("SNAPPY", b"\x05\x10abcd", 5)[0] == D            # literal runs past the stream
+    assert orc.decompress("SNAPPY", b"\x06\x10abcde", 5)[0] == D           # preamble disagrees
+    assert orc.decompress("SNAPPY", b"\x05\x00a\x01\x02", 5)[0] == D       # offset beyond what was produced
+    assert orc.decompress("SNAPPY", b"\x05\x00a\x01\x00", 5)[0] == D       # offset 0
+    assert orc.decompress("SNAPPY", b"\x05\x00a\x01\x01", 5)[:2][1].tobytes() == b"aaaaa"
+    assert orc.decompress("SNAPPY", b"\x80\x80\x80\x80\x80\x01", 0)[0] == D  # preamble longer than a varint32
+    assert orc.decompress("LZ4_RAW", b"", 0)[0] == 0
+    assert orc.decompress("LZ4_RAW", b"\x10a", 1)[0] == 0
+    assert orc.decompress("LZ4_RAW", b"\x10a", 2)[0] == D                  # short of the announced size
+    assert orc.decompress("LZ4_RAW", b"\x20a", 2)[0] == D                  # literals run past the stream
+    assert orc.decompress("LZ4_RAW", b"\x10a\x00\x00", 5)[0] == D          # offset 0
+    assert orc.decompress("LZ4_RAW", b"\x10a\x02\x00", 5)[0] == D          # offset beyond what was produced
+    assert orc.decompress("LZ4_RAW", b"\x10a\x01", 5)[0] == D              # half an offset
+    assert orc.decompress("LZ4_RAW", b"\x1fa\x01\x00\xff", 300)[0] == D    # length bytes run out
+    assert orc.decompress("LZ4_RAW", b"\x10a\x01\x00", 5)[:2][1].tobytes() == b"aaaaa"
+
+
+# ------------------------------------------------------------------------------- GPU
+def run_batch(pq, gh, torch, codec, items, misalign=3):
+    """items: (stream, announced size); one pqd_decompress_pages_dev call.  -> [(status, bytes, consumed)]"""
+    n = len(items)
+    descs = (pq.DecompressDesc * n)()
+    src_at, pos = [], misalign
+    for stream, size in items:
+        src_at.append(pos)
+        pos += len(stream) + 1  # back to back at odd addresses
+    blob = np.full(pos + 64, 0xEE, np.uint8)
+    for (stream, size), a in zip(items, src_at):
+        blob[a:a + len(stream)] = np.frombuffer(bytes(stream), np.uint8)
+    d_blob = gh.to_dev(blob)
+    dst_at, pos = [], 5
+    for stream, size in items:
+        dst_at.append(pos)
+        pos += size + 7
+    d_out = torch.full((pos + 64,), 0xA5, dtype=torch.uint8, device=gh.dev())
+    for i, (stream, size) in enumerate(items):
+        descs[i].src, descs[i].dst = d_blob.data_ptr() + src_at[i], d_out.data_ptr() + dst_at[i]
+        descs[i].src_len, descs[i].dst_len, descs[i].codec = len(stream), size, codec
+    d_descs = gh.to_dev(np.frombuffer(bytes(descs), np.uint8).copy())
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=gh.dev())
+    pq.check(pq.lib.pqd_decompress_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n, codec, None))
+    torch.cuda.synchronize()
+    raw = d_res.cpu().numpy().view(np.uint32).reshape(-1, 4)
+    out = d_out.cpu().numpy()
+    res = []
+    for i, (stream, size) in enumerate(items):
+        st, made, used = int(raw[i, 0]), int(raw[i, 1]), int(raw[i, 2])
+        assert made <= size
+        assert (out[dst_at[i] + size:dst_at[i] + size + 7] == 0xA5).all() and (out[dst_at[i] - 5:dst_at[i]] == 0xA5).all(), \
+            "bytes written outside the page"
+        res.append((st, out[dst_at[i]:dst_at[i] + made].tobytes(), used))
+    return res
+
+
+def check_batch(orc, codec_name, items, results):
+    for (stream, size), (st, data, used) in zip(items, results):
+        ost, odata, oused = orc.decompress(codec_name, stream, size)
+        assert st == ost, (st, ost, len(stream), size)
+        assert data == bytes(odata)
+        assert used == oused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    items, want = [], []
+    for v in VECTORS:
+        if v["codec"] == codec_name:
+            items.append((base64.b64decode(v["compressed"]), v["size"]))
+            want.append(ORIGINALS[v["name"]])
+    stream, raw = handmade_snappy() if codec_name == "SNAPPY" else handmade_lz4()
+    items.append((stream, len(raw)))
+    want.append(raw)
+    for fx in PAGES:
+        if ("SNAPPY" if fx["codec"] == "SNAPPY" else "LZ4_RAW") == codec_name:
+            for body, size in compressed_parts(fx):
+                items.append((body, size))
+                want.append(None)
+    for misalign in (0, 3):
+        results = run_batch(pq, gh, torch, CODEC_NUM[codec_name], items, misalign)
+        check_batch(orc, codec_name, items, results)
+        for (st, data, used), w in zip(results, want):
+            assert st == 0 and (w is None or data == w)
+    # announced sizes that do not fit the stream
+    wrong = [(s, size + 1) for s, size in items[:8]] + [(s, size - 1) for s, size in items[:8] if size]
+    check_batch(orc, codec_name, wrong, run_batch(pq, gh, torch, CODEC_NUM[codec_name], wrong))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+def test_gpu_damaged_streams(orc, codec_name):
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(123)
+    base = [(base64.b64decode(v["compressed"]), v["size"]) for v in VECTORS
+            if v["codec"] == codec_name and v["name"] in ("short", "text", "ints", "mixed", "run_3", "timestamps")]
+    items = []
+    for trial in range(150):
+        stream, size = base[trial % len(base)]
+        stream = bytearray(stream[:4000]) if trial % 2 else bytearray(stream)
+        for _ in range(int(rng.integers(1, 4))):
+            stream[int(rng.integers(0, min(len(stream), 600)))] = int(rng.integers(0, 256))
+        if trial % 7 == 0:
+            stream = stream[:int(rng.integers(0, len(stream)))]
+        items.append((bytes(stream), size))
+    check_batch(orc, codec_name, items, run_batch(pq, gh, torch, CODEC_NUM[codec_name], items))
+
+
+@pytest.mark.gpu
+def test_gpu_stored_parts_and_host_entry(orc):
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(7)
+    items = [(bytes(rng.integers(0, 256, n, dtype=np.uint8)), n) for n in (0, 1, 15, 16, 17, 1000, 70001)]
+    for (stream, size), (st, data, used) in zip(items, run_batch(pq, gh, torch, 0, items)):
+        assert st == 0 and data == stream and used == size
+    (st, data, used), = run_batch(pq, gh, torch, 0, [(b"abcdef", 4)])
+    assert st == orc.DECODE and data == b"abcd"
+    assert pq.lib.pqd_codec_supported(1) and pq.lib.pqd_codec_supported(7) and not pq.lib.pqd_codec_supported(2)
+    # the host entry behind the BytesDecompressor mirror
+    for name in ("SNAPPY", "LZ4_RAW"):
+        d = pq.BytesDecompressor(name)
+        for v in VECTORS:
+            if v["codec"] == name and v["name"] in ("empty", "short", "text", "random"):
+                assert d.decompress(base64.b64decode(v["compressed"]), v["size"]) == ORIGINALS[v["name"]]
+        with pytest.raises(IOError):
+            d.decompress(b"\x05\x10abcd", 5)
+    with pytest.raises(pq.IllegalArgumentException):
+        pq.BytesDecompressor("GZIP")
