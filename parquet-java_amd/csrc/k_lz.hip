@@ -8,7 +8,7 @@
 // "repeat `length` bytes from `offset` back" elements, so a page is one serial chain; pages are
 // independent.  One wave per page: the element headers are decoded wave-uniformly (scalar registers), the
 // 64 lanes move the bytes.  The input is staged in LDS in 2 KiB chunks, the next chunk already on its way
-// in registers; the last 32 KiB of output are kept in an LDS ring, which is where nearly every match
+// in registers, and the headers are read from a 16-byte window of it kept in scalar registers; the last 32 KiB of output are kept in an LDS ring, which is where nearly every match
 // reads from (a match from further back reads the bytes back from memory).  Lane l of a match step takes
 // the byte `offset` back, or for offsets below 64 the byte (l mod offset) - offset back of the step's
 // start, which is the same byte of the repeating pattern and always already written.
@@ -71,6 +71,31 @@ struct InStage {
   }
   __device__ __forceinline__ uint32_t byte(uint32_t pos) const { return lds[pos & (LZ_STAGE - 1u)]; }
   __device__ __forceinline__ uint32_t ubyte(uint32_t pos) const { return uni(byte(pos)); }
+
+  // The element headers are read from a 16-byte window held in scalar registers: win0 = the eight
+  // bytes at the 8-aligned position win_at, win1 the eight behind them.  The window moves on in steps
+  // of eight bytes; the half that comes in is requested from LDS when the step is taken and is not
+  // needed before the headers have moved past the half in front of it, so its latency is hidden.
+  uint64_t win0, win1;
+  uint32_t win_at;
+  __device__ __forceinline__ uint64_t load8(uint32_t pos8) const {  // pos8: a multiple of 8 inside the staged chunks
+    const u32x2 v = *reinterpret_cast<const u32x2*>(lds + (pos8 & (LZ_STAGE - 1u)));
+    return ((uint64_t)uni(v.y) << 32) | uni(v.x);
+  }
+  // the eight bytes at `pos` (reach(pos) has been called; pos + 8 may lie one chunk further)
+  __device__ __forceinline__ uint64_t peek8(uint32_t pos) {
+    if (pos - win_at >= 16u) {  // a jump (long literal, first use): both halves anew
+      win_at = pos & ~7u;
+      win0 = load8(win_at);
+      win1 = load8(win_at + 8u);
+    } else if (pos - win_at >= 8u) {
+      win_at += 8u;
+      win0 = win1;
+      win1 = load8(win_at + 8u);
+    }
+    const uint32_t sh = (pos - win_at) * 8u;
+    return sh ? (win0 >> sh) | (win1 << (64u - sh)) : win0;
+  }
 };
 
 struct OutRing {
@@ -97,7 +122,14 @@ struct OutRing {
     }
   }
   __device__ __forceinline__ void match(uint32_t op, uint32_t offset, uint32_t len) {
-    const uint32_t lm = offset >= 64u ? lane : lane % offset;
+    uint32_t lm = lane;  // lane mod offset for offsets below 64: six conditional subtractions
+    if (offset < 64u) {
+#pragma unroll
+      for (int k = 5; k >= 0; --k) {
+        const uint32_t t = offset << k;
+        lm = lm >= t ? lm - t : lm;
+      }
+    }
     if (offset <= LZ_RING) {
       for (uint32_t b = 0; b < len; b += 64u) {
         if (b + lane < len) {
@@ -144,6 +176,8 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
   in.lds = s_stage;
   in.cur = 0;
   in.start(0);
+  in.win_at = 0x80000000u;  // nothing in the window yet
+  in.win0 = in.win1 = 0;
   OutRing out = {s_ring, d.dst, lane};
   const uint32_t cap = d.dst_len, in_end = in.end;
   uint32_t ip = skew, op = 0;
@@ -155,7 +189,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     uint32_t shift = 0;
     bool ok = false;
     while (ip < in_end && shift <= 28u) {
-      const uint32_t b = in.ubyte(ip);
+      const uint32_t b = (uint32_t)in.peek8(ip) & 0xFFu;
       ++ip;
       ulen |= (uint64_t)(b & 0x7Fu) << shift;
       if (!(b & 0x80u)) {
@@ -170,8 +204,9 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     } else {
       while (ip < in_end) {
         in.reach(ip);
-        const uint32_t tag = in.ubyte(ip);
-        const uint32_t rest = uni(in.byte(ip + 1) | (in.byte(ip + 2) << 8) | (in.byte(ip + 3) << 16) | (in.byte(ip + 4) << 24));
+        const uint64_t head = in.peek8(ip);
+        const uint32_t tag = (uint32_t)head & 0xFFu;
+        const uint32_t rest = (uint32_t)(head >> 8);
         const uint32_t left = in_end - ip;
         const uint32_t kind = tag & 3u;
         if (kind == 0u) {
@@ -224,7 +259,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
   } else {  // LZ4 block
     while (ip < in_end) {
       in.reach(ip);
-      const uint32_t token = in.ubyte(ip);
+      const uint32_t token = (uint32_t)in.peek8(ip) & 0xFFu;
       ++ip;
       uint64_t lit = token >> 4;
       bool bad = false;
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
             break;
           }
           in.reach(ip);
-          b = in.ubyte(ip);
+          b = (uint32_t)in.peek8(ip) & 0xFFu;
           ++ip;
           lit += b;
         } while (b == 255u);
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
         break;
       }
       in.reach(ip);
-      const uint32_t offset = uni(in.byte(ip) | (in.byte(ip + 1) << 8));
+      const uint32_t offset = (uint32_t)in.peek8(ip) & 0xFFFFu;
       ip += 2u;
       uint64_t mlen = token & 15u;
       if (mlen == 15u) {
@@ -266,7 +301,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
             break;
           }
           in.reach(ip);
-          b = in.ubyte(ip);
+          b = (uint32_t)in.peek8(ip) & 0xFFu;
           ++ip;
           mlen += b;
         } while (b == 255u);

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                                                                   RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
                                                                   uint32_t n_pages, int want_dict, int elem,
-                                                                  DictPlanes planes) {
+                                                                  DictPlanes planes, int small_ran) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
@@ -555,6 +555,13 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   if (page >= n_pages) return;
   const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
+  if (small_ran && plans[page].flags == PLAN_F_SMALL_DONE) {  // k_rle_small_pages has decoded this page
+    if (tid == 0) {
+      plans[page].flags = PLAN_F_DONE;
+      if (page < pool_chunks) write_empty_chunk(pool, page);
+    }
+    return;
+  }
 
   // ---- validation and stream prefixes (same rules as the generic kernel)
   int32_t early = PQD_OK;
@@ -978,13 +985,18 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
 
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
-                                  const DictPlanes& planes, hipStream_t stream) {
+                                  const DictPlanes& planes, bool try_small, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   if (want_dict && elem == 8 && planes.n_slots != 0)
     hipLaunchKernelGGL(k_dict_slots, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, descs, n_pages, cursor, planes);
+  const bool small = try_small && !want_dict && elem == 4;
+  if (small) {  // small pages first: what it decodes the plan kernel skips
+    hipError_t e = launch_rle_small_pages(descs, results, plans, n_pages, stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
                      reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
-                     want_dict ? 1 : 0, elem, planes);
+                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -326,6 +326,12 @@ bool use_planned_rle_path() {
   return !(v && strcmp(v, "generic") == 0);
 }
 
+// PQD_RLE_SMALL=0 keeps small hybrid pages on the planned kernels (k_rle_small_pages is skipped).
+bool use_small_rle_kernel() {
+  const char* v = getenv("PQD_RLE_SMALL");
+  return !(v && strcmp(v, "0") == 0);
+}
+
 int class_of(const pqd_page_desc& d) {  // pages that can share a launch
   return ((int)d.encoding << 8) | (int)(d.encoding == PQD_ENC_BYTE_STREAM_SPLIT || d.encoding == PQD_ENC_PLAIN ? 0 : d.elem_size);
 }
@@ -572,7 +578,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(hipMemsetAsync(ps.counters, 0, COUNTER_BYTES, s));
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4,
-                                            pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, s));
+                                            pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, use_small_rle_kernel(), s));
         PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, ps.counters, n_pages, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, ps.counters + 1, s));
       }
@@ -597,7 +603,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if ((st = phase_mark(0, s))) return st;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, true,
-                                            elem_size, planes, s));
+                                            elem_size, planes, false, s));
         PQD_HIP(pqd::launch_dict_planes(planes, ps.counters, s));
         if ((st = phase_mark(1, s))) return st;
         PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, planes.area, s));
@@ -679,7 +685,8 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
   // the array keeps the last call's contents: the counters and the plane key table must start at
   // zero; plans, chunks and plane copies are written by the kernels before anything reads them
   PQD_HIP(hipMemsetAsync(counters, 0, COUNTER_BYTES + PLANE_KEYS_BYTES, s));
-  PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, planes, s));
+  PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, planes,
+                                      use_small_rle_kernel(), s));
   if (dict) {
     PQD_HIP(pqd::launch_dict_planes(planes, counters, s));
     PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, planes.area, s));

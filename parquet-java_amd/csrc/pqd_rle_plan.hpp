@@ -59,6 +59,7 @@ struct RleChunkHead {
 static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
 
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
+constexpr uint32_t PLAN_F_SMALL_DONE = 4u;  // decoded by k_rle_small_pages before the plan kernel ran (which turns it into PLAN_F_DONE)
 constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel
 
 // Sliced dictionary gather: LDS slice size and the values one workgroup holds in registers per

@@ -43,3 +43,24 @@ def gather_summaries(local_summary, group=None):
     out = [None] * dist.get_world_size(group)
     dist.all_gather_object(out, local_summary, group=group)
     return out
+
+
+def decode_row_groups(row_groups, rank: int, world_size: int, stream=None, sizes=None, policy: str = "round_robin"):
+    """Decodes the row groups `rank` owns, one ``pqd_decode_pages`` call per row group.
+
+    row_groups[g] is a ctypes array of ``PageDesc`` (host descriptors; data, dictionaries and outputs in
+    this rank's device memory).  Returns ``{g: (PageResult array, summary dict)}`` for the owned groups;
+    the summaries (pages, values, failed pages) are what ``gather_summaries`` collects."""
+    import ctypes as C
+
+    from . import PageResult, check, lib
+    mine = assign_row_groups(sizes if sizes is not None else [len(g) for g in row_groups], world_size, policy)[rank]
+    out = {}
+    for g in mine:
+        descs = row_groups[g]
+        n = len(descs)
+        results = (PageResult * n)()
+        check(lib.pqd_decode_pages(descs, results, n, C.c_void_p(stream) if stream else None), "pqd_decode_pages")
+        out[g] = (results, dict(group=g, pages=n, values=sum(r.values_written for r in results),
+                                failed=[i for i, r in enumerate(results) if r.status != 0]))
+    return out

@@ -28,8 +28,11 @@ def dict_path(request, monkeypatch):
     return request.param
 
 
-@pytest.fixture(params=["generic", "planned"])
+@pytest.fixture(params=["generic", "planned", "planned-no-small"])
 def rle_path(request, monkeypatch):
-    """Runs a test once per kernel path of plain hybrid pages (PQD_RLE_PATH, read on every call)."""
-    monkeypatch.setenv("PQD_RLE_PATH", request.param)
+    """Runs a test once per kernel path of plain hybrid pages (PQD_RLE_PATH / PQD_RLE_SMALL, read on every
+    call): the generic kernel alone; the planned kernels with the small-page kernel in front; the planned
+    kernels alone."""
+    monkeypatch.setenv("PQD_RLE_PATH", "generic" if request.param == "generic" else "planned")
+    monkeypatch.setenv("PQD_RLE_SMALL", "0" if request.param == "planned-no-small" else "1")
     return request.param

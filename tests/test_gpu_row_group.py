@@ -76,3 +76,63 @@ def test_mixed_row_group_in_one_call(orc):
         assert results[i].status == 0 and results[i].values_written == nv, (i, enc, results[i].status)
         got = out[offs[i]:offs[i] + nv * elem].view(exp.dtype)
         assert (got == exp).all(), (i, enc)
+
+
+def test_sharded_row_groups_decode_their_own_pages(orc):
+    """The sharding of the multi-GPU workload driving real decodes: twelve row groups of mixed pages, assigned to
+    1, 2 and 3 ranks; each rank's share is decoded with one pqd_decode_pages call per row group (all ranks
+    take their turn on the one GPU of the test box) and every page is checked against the oracle."""
+    import torch
+    import parquet_java_amd as pq
+    from parquet_java_amd.shard import assign_row_groups, decode_row_groups, gather_summaries
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(77)
+    n = 5000
+    d64 = rng.integers(-(1 << 62), 1 << 62, 3000).astype(np.int64)
+    d_dict = gh.to_dev(d64.view(np.uint8))
+    keep, groups, expect, sizes = [], [], [], []
+    for g in range(12):
+        pages = []
+        for c in range(1 + g % 3):  # groups of different weight
+            ids = rng.integers(0, d64.size, n).astype(np.int32)
+            pages.append((orc.dict_encode_ids(ids, d64.size), pq.ENC_RLE_DICTIONARY, 8, 0, 0, d64[ids]))
+            ts = np.cumsum(rng.integers(0, 1 << 10, n)).astype(np.int64)
+            pages.append((orc.delta_encode(ts), pq.ENC_DELTA_BINARY_PACKED, 8, 0, 0, ts))
+            lv = (rng.random(n) < 0.8).astype(np.int32)
+            pages.append((orc.rle_encode(1, lv), pq.ENC_RLE, 4, 1, 0, lv))
+            fl = rng.standard_normal(n).astype(np.float32)
+            pages.append((fl.tobytes(), pq.ENC_PLAIN, 4, 0, 0, fl.view(np.int32)))
+        blob = gh.to_dev(np.concatenate([np.frombuffer(bytes(p[0]), np.uint8) for p in pages]))
+        out = torch.zeros(sum(n * p[2] for p in pages) + 64, dtype=torch.uint8, device=gh.dev())
+        descs = (pq.PageDesc * len(pages))()
+        pos = opos = 0
+        where = []
+        for i, (data, enc, elem, bw, flags, exp) in enumerate(pages):
+            descs[i].data, descs[i].data_len, descs[i].out, descs[i].num_values = blob.data_ptr() + pos, len(bytes(data)), out.data_ptr() + opos, n
+            descs[i].encoding, descs[i].elem_size, descs[i].bit_width, descs[i].flags = enc, elem, bw, flags
+            if enc == pq.ENC_RLE_DICTIONARY:
+                descs[i].dict, descs[i].dict_len = d_dict.data_ptr(), d64.size
+            where.append((opos, n * elem, exp))
+            pos += len(bytes(data))
+            opos += n * elem
+        keep.append((blob, out))
+        groups.append(descs)
+        expect.append(where)
+        sizes.append(int(blob.numel()))
+    stream = torch.cuda.current_stream().cuda_stream
+    for world, policy in ((1, "round_robin"), (2, "round_robin"), (3, "greedy")):
+        for _, out in keep:
+            out.zero_()
+        owned = assign_row_groups(sizes, world, policy)
+        assert sorted(g for part in owned for g in part) == list(range(12))
+        for rank in range(world):
+            done = decode_row_groups(groups, rank, world, stream, sizes, policy)
+            assert sorted(done) == owned[rank]
+            summaries = gather_summaries([s for _, s in done.values()])  # no process group here: the local list
+            assert all(not s["failed"] and s["values"] == s["pages"] * n for s in summaries[0])
+        torch.cuda.synchronize()
+        for (blob, out), where in zip(keep, expect):
+            host = out.cpu().numpy()
+            for opos, nbytes, exp in where:
+                assert (host[opos:opos + nbytes].view(exp.dtype) == exp).all()
