@@ -24,7 +24,6 @@ constexpr uint32_t BN_TILE = BN_THREADS * BN_VPL;
 constexpr uint32_t BN_WIN = 24 * 1024;  // output bytes staged per window
 constexpr uint32_t BN_NONE = 0xFFFFFFFFu;
 
-#define PQD_GLOBAL __attribute__((address_space(1)))
 
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint64_t u64_a8 __attribute__((aligned(8)));

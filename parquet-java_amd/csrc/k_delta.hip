@@ -29,7 +29,6 @@ constexpr int MAX_MINIS = 896;      // miniblock table entries per window
 constexpr int MAX_MINI_PER_BLOCK = 256;
 constexpr int MAX_FAST_BLOCKS = DELTA_THREADS;  // blocks per window whose headers are expanded one per lane
 
-#define PQD_LDS __attribute__((address_space(3)))
 typedef const PQD_LDS uint32_t* lds_words_t;
 
 __device__ __forceinline__ uint32_t ldsb(lds_words_t w, uint32_t off) { return (w[off >> 2] >> ((off & 3u) * 8u)) & 0xFFu; }
@@ -185,7 +184,7 @@ __device__ __forceinline__ void delta_page(const pqd_page_desc& d, pqd_page_resu
   // miniblocks of 2^k values (the writers' 32): a shift instead of a division per lane and tile
   const uint32_t mini_shift = (mini_size & (mini_size - 1)) == 0 && mini_size ? (uint32_t)__builtin_ctz(mini_size) : ~0u;
   acc_t carry = (acc_t)st.first;  // value at output index deltas_done
-  acc_t* out = reinterpret_cast<acc_t*>(d.out);
+  PQD_GLOBAL acc_t* out = (PQD_GLOBAL acc_t*)d.out;
   bool first_window = true;
   constexpr int NEXT_PIECES = (DWINDOW_PIECES + DELTA_THREADS - 1) / DELTA_THREADS;
   u32x4 next_win[NEXT_PIECES];  // the next window on its way from memory while this one is unpacked
@@ -389,7 +388,7 @@ __device__ __forceinline__ void delta_page(const pqd_page_desc& d, pqd_page_resu
         const int i = (int)tid + j * DELTA_THREADS;
         const uint8_t* q = nbase + (size_t)i * 16;
         next_win[j] = u32x4{0u, 0u, 0u, 0u};
-        if (i < DWINDOW_PIECES && q < gend) next_win[j] = *reinterpret_cast<const u32x4*>(q);
+        if (i < DWINDOW_PIECES && q < gend) next_win[j] = *(const PQD_GLOBAL u32x4*)(q);
       }
     }
     // one lane per block found by the quick walk: min delta, widths -> miniblock table entries
@@ -478,11 +477,11 @@ __device__ __forceinline__ void delta_page(const pqd_page_desc& d, pqd_page_resu
           if (ELEM == 8) {
             u32x4_a4 r0 = {(uint32_t)o0, (uint32_t)((uint64_t)o0 >> 32), (uint32_t)o1, (uint32_t)((uint64_t)o1 >> 32)};
             u32x4_a4 r1 = {(uint32_t)o2, (uint32_t)((uint64_t)o2 >> 32), (uint32_t)o3, (uint32_t)((uint64_t)o3 >> 32)};
-            *reinterpret_cast<u32x4_a4*>(out + g0) = r0;
-            *reinterpret_cast<u32x4_a4*>(out + g0 + 2) = r1;
+            *(PQD_GLOBAL u32x4_a4*)(out + g0) = r0;
+            *(PQD_GLOBAL u32x4_a4*)(out + g0 + 2) = r1;
           } else {
             u32x4_a4 r = {(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)o3};
-            *reinterpret_cast<u32x4_a4*>(out + g0) = r;
+            *(PQD_GLOBAL u32x4_a4*)(out + g0) = r;
           }
         } else {
           if (g0 < total) out[g0] = o0;

@@ -157,7 +157,7 @@ __device__ __forceinline__ uint32_t shuffle_u32(uint32_t v, uint32_t from_lane) 
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
 }
 
-__device__ __forceinline__ uint8_t load_written_byte(const uint8_t* p) {
+__device__ __forceinline__ uint8_t load_written_byte(const PQD_GLOBAL uint8_t* p) {
   // bytes this wave stored a moment ago: read them where the stores went (past the vector L1)
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -181,20 +181,21 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     }
     return;
   }
-  const int32_t* prefix = reinterpret_cast<const int32_t*>(b.work + DELTA_BYTES_WORK_HEADER);
-  const int32_t* suffix = prefix + b.num_values;
+  const PQD_GLOBAL int32_t* prefix = (const PQD_GLOBAL int32_t*)(b.work + DELTA_BYTES_WORK_HEADER);
+  const PQD_GLOBAL int32_t* suffix = prefix + b.num_values;
+  PQD_GLOBAL int32_t* offsets = (PQD_GLOBAL int32_t*)b.offsets;
   const uint32_t n = lb.n;
-  const uint8_t* sdata = b.data + lb.header;
+  const PQD_GLOBAL uint8_t* sdata = (const PQD_GLOBAL uint8_t*)b.data + lb.header;
   const uint64_t savail = b.data_len - lb.header;
   const uint64_t cap = b.bytes_capacity > 0x7fffffffu ? 0x7fffffffull : (uint64_t)b.bytes_capacity;
 
   // the value before the page
   uint32_t last_len = 0;
-  const uint8_t* last_ptr = nullptr;  // its bytes in global memory (for prefixes longer than `keep`)
+  const PQD_GLOBAL uint8_t* last_ptr = nullptr;  // its bytes in global memory (for prefixes longer than `keep`)
   if (b.prev_bytes && b.prev_offsets && b.prev_count) {
     const int32_t p0 = b.prev_offsets[b.prev_count - 1], p1 = b.prev_offsets[b.prev_count];
     last_len = p1 > p0 ? (uint32_t)(p1 - p0) : 0u;
-    last_ptr = b.prev_bytes + p0;
+    last_ptr = (const PQD_GLOBAL uint8_t*)b.prev_bytes + p0;
     for (uint32_t t = lane; t < last_len && t < DB_KEEP; t += 64) keep[t] = last_ptr[t];
   }
 
@@ -225,19 +226,19 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     const uint64_t unfit_mask = __ballot(!fits);
     uint32_t m = unfit_mask ? (uint32_t)__builtin_ctzll(unfit_mask) : 64u;
     m = m < deliverable ? m : deliverable;
-    uint8_t* dst = b.bytes + run_out;
+    PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)b.bytes + run_out;
     if (m == 0) {
       // one value through global memory: its prefix from where the value before it was written
       const uint32_t p0 = __builtin_amdgcn_readfirstlane(p), s0 = __builtin_amdgcn_readfirstlane(s);
       __threadfence();
       for (uint32_t t = lane; t < p0; t += 64) dst[t] = load_written_byte(last_ptr + t);
-      const uint8_t* src = sdata + run_in;
+      const PQD_GLOBAL uint8_t* src = sdata + run_in;
       for (uint32_t t = lane; t < s0; t += 64) {
         const uint8_t v = src[t];
         dst[p0 + t] = v;
         if (p0 + t < DB_KEEP) keep[p0 + t] = v;
       }
-      if (lane == 0) b.offsets[i0] = (int32_t)run_out;
+      if (lane == 0) offsets[i0] = (int32_t)run_out;
       last_ptr = dst;
       last_len = p0 + s0;
       run_out += (uint64_t)p0 + s0;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     const bool mine = lane < m;
     // suffix bytes of the batch -> LDS
     {
-      const uint8_t* src = sdata + run_in;
+      const PQD_GLOBAL uint8_t* src = sdata + run_in;
       const uint64_t left = savail - run_in;  // bytes that exist behind src
       for (uint32_t t = lane * 16u; t < in_bytes; t += 1024u) {
         if ((uint64_t)t + 16u <= left) {
@@ -315,15 +316,15 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
         }
       }
     }
-    if (mine) b.offsets[idx] = (int32_t)(run_out + oo);
+    if (mine) offsets[idx] = (int32_t)(run_out + oo);
     __syncthreads();
     // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
     {
-      uint8_t* gbase = dst - a;  // 16-byte aligned
+      PQD_GLOBAL uint8_t* gbase = dst - a;  // 16-byte aligned
       const uint32_t end = a + out_bytes;
       for (uint32_t t = lane * 16u; t < end; t += 1024u) {
         if (t >= a && t + 16u <= end) {
-          *reinterpret_cast<u32x4*>(gbase + t) = *reinterpret_cast<const u32x4*>(out_tile + t);
+          *(PQD_GLOBAL u32x4*)(gbase + t) = *reinterpret_cast<const u32x4*>(out_tile + t);
         } else {
           for (uint32_t k = 0; k < 16u; ++k)
             if (t + k >= a && t + k < end) gbase[t + k] = out_tile[t + k];
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
   }
   if (status == PQD_OK && i0 < b.num_values) status = PQD_DECODE;  // "no more value to read" from a length block
   if (lane == 0) {
-    b.offsets[i0] = (int32_t)run_out;
+    offsets[i0] = (int32_t)run_out;
     pqd_page_result r = {status, i0, lb.header + (uint32_t)run_in, (uint32_t)run_out};
     results[page] = r;
   }

@@ -56,8 +56,6 @@ static_assert(DS_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(DS_OFF_STATE % 16 == 0, "state block alignment");
 static_assert(DS_R % 4 == 0 && DS_R <= 32, "a lane holds whole units, one flag bit per value");
 
-#define PQD_GLOBAL __attribute__((address_space(1)))
-#define PQD_LDS __attribute__((address_space(3)))
 
 // Build with -DPQD_PROF for per-phase cycle counts (development only; see the Makefile's prof target).
 #ifdef PQD_PROF

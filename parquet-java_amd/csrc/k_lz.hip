@@ -12,7 +12,10 @@
 // reads from (a match from further back reads the bytes back from memory).  Lane l of a match step takes
 // the byte `offset` back, or for offsets below 64 the byte (l mod offset) - offset back of the step's
 // start, which is the same byte of the repeating pattern and always already written.
-// Bound by the serial element chain (LDS latency per element), not by HBM.
+// Bound by the serial element chain, not by HBM: a wave spends several hundred cycles per element (scalar
+// decode, branches, one LDS round trip for the bytes), which is about 20 MB/s per page in flight, and LDS
+// holds four pages per CU.  (Buffering the output in the ring and writing it in 16-byte pieces, instead of
+// storing each element's bytes, was measured and is slower: the stores are not what the chain waits for.)
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 
@@ -24,8 +27,9 @@ constexpr uint32_t LZ_STAGE = 2 * LZ_CHUNK;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// (Memory is addressed through global-space pointers: see PQD_GLOBAL.)
 struct InStage {
-  const uint8_t* base;  // the source, rounded down to 16 bytes; positions below count from here
+  const PQD_GLOBAL uint8_t* base;  // the source, rounded down to 16 bytes; positions below count from here
   uint32_t end;         // position behind the last source byte
   uint32_t cur;         // chunks cur and cur + 1 are in LDS, chunk cur + 2 in pre0 / pre1
   uint32_t lane;
@@ -36,8 +40,8 @@ struct InStage {
     const uint32_t p = c * LZ_CHUNK + lane * 32u;
     r0 = u32x4{0u, 0u, 0u, 0u};
     r1 = r0;
-    if (p < end) r0 = *reinterpret_cast<const u32x4*>(base + p);
-    if (p + 16u < end) r1 = *reinterpret_cast<const u32x4*>(base + p + 16u);
+    if (p < end) r0 = *reinterpret_cast<const PQD_GLOBAL u32x4*>(base + p);
+    if (p + 16u < end) r1 = *reinterpret_cast<const PQD_GLOBAL u32x4*>(base + p + 16u);
   }
   __device__ __forceinline__ void put(uint32_t c, u32x4 r0, u32x4 r1) {
     u32x4* d = reinterpret_cast<u32x4*>(lds + (c & 1u) * LZ_CHUNK + lane * 32u);
@@ -100,7 +104,7 @@ struct InStage {
 
 struct OutRing {
   uint8_t* ring;
-  uint8_t* dst;
+  PQD_GLOBAL uint8_t* dst;
   uint32_t lane;
 
   // `len` literal bytes from the staged input (they lie within the staged chunks) or, long ones, from memory
@@ -112,7 +116,7 @@ struct OutRing {
         dst[op + i] = v;
       }
     } else {
-      const uint8_t* src = in.base + from;
+      const PQD_GLOBAL uint8_t* src = in.base + from;
 #pragma unroll 4
       for (uint32_t i = lane; i < len; i += 64u) {
         const uint8_t v = src[i];
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     return;
   }
   InStage in;
-  in.base = reinterpret_cast<const uint8_t*>((uintptr_t)d.src & ~(uintptr_t)15);
-  const uint32_t skew = (uint32_t)(d.src - in.base);
+  in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
+  const uint32_t skew = (uint32_t)((uintptr_t)d.src & 15u);
   in.end = skew + d.src_len;
   in.lane = lane;
   in.lds = s_stage;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
   in.start(0);
   in.win_at = 0x80000000u;  // nothing in the window yet
   in.win0 = in.win1 = 0;
-  OutRing out = {s_ring, d.dst, lane};
+  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane};
   const uint32_t cap = d.dst_len, in_end = in.end;
   uint32_t ip = skew, op = 0;
   int32_t status = PQD_OK;

@@ -20,8 +20,6 @@ constexpr int EX_UNITS = 4;                                  // units per lane p
 constexpr uint32_t EX_TILE = EX_THREADS * EX_UNITS * 4;      // 4096 values
 static_assert(EX_THREADS * 4 % SEG_BLOCK == 0 && SEG_BLOCK == 256, "a wave's unit row is one table block");
 
-#define PQD_GLOBAL __attribute__((address_space(1)))
-#define PQD_LDS __attribute__((address_space(3)))
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     return;
   }
   const uint32_t N = end - pos;
-  const uint8_t* src = d.data + pos;
+  const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.data + pos;
 #ifdef PQD_PROF
   uint64_t stamp[10];
   int n_stamp = 0;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   RS_STAMP();
   // ---- 5. values, four per thread and step
   const uint32_t mask = (1u << w) - 1u;
-  uint32_t* out = reinterpret_cast<uint32_t*>(d.out);
+  PQD_GLOBAL uint32_t* out = (PQD_GLOBAL uint32_t*)d.out;
 #pragma unroll 2
   for (uint32_t v0 = tid * 4u; v0 < n_values; v0 += RS_THREADS * 4u) {
     const uint32_t wd = v0 >> 6, sh = v0 & 63u;  // the four values share a word of the bitmap
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     }
     if (v0 + 4u <= n_values) {
       const u32x4_a4 q = {val[0], val[1], val[2], val[3]};
-      PQD_STREAM_STORE(reinterpret_cast<u32x4_a4*>(out + v0), q);
+      PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(out + v0), q);
     } else {
       for (uint32_t k = 0; v0 + k < n_values; ++k) out[v0 + k] = val[k];
     }

@@ -11,6 +11,13 @@
 // (dictionary slices, plan chunks) and fill the write-back capacity in bursts.
 #define PQD_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 
+// Pointers that come out of descriptors in memory are generic to the compiler, and accesses through
+// generic pointers are FLAT instructions: those count as LDS operations as well, so a kernel that waits
+// for an LDS read then also waits for its outstanding stores.  Kernels that mix LDS and memory traffic
+// cast such pointers to the global address space once.
+#define PQD_GLOBAL __attribute__((address_space(1)))
+#define PQD_LDS __attribute__((address_space(3)))
+
 namespace pqd {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -91,7 +98,7 @@ __device__ __forceinline__ void stage_window(u32x4* lds, const uint8_t* gbase, c
       const uint8_t* p = gbase + (size_t)i * 16;
       valid[j] = i < pieces ? (long)(gend - p) : 0;
       v[j] = u32x4{0u, 0u, 0u, 0u};
-      if (valid[j] > 0) v[j] = *reinterpret_cast<const u32x4*>(p);
+      if (valid[j] > 0) v[j] = *(const PQD_GLOBAL u32x4*)(p);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
