@@ -123,20 +123,37 @@ __global__ __launch_bounds__(256) void k_bitpacked_pages(const pqd_page_desc* __
   const uint32_t n = d.num_values;
   uint64_t length = ((uint64_t)n * w + 7) >> 3;  // :78-79
   if (length > d.data_len) length = d.data_len;  // :84
-  uint32_t* out = reinterpret_cast<uint32_t*>(d.out);
+  PQD_GLOBAL uint32_t* out = (PQD_GLOBAL uint32_t*)d.out;
+  const PQD_GLOBAL uint8_t* data = (const PQD_GLOBAL uint8_t*)d.data;
   const uint32_t mask = mask32(w);
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    // group g = i/8 starts at byte g*w; a group whose bytes run past `length` is zero-filled (:48-57)
+  // one value from the five bytes around it (a group whose bytes run past `length` is zero-filled, :48-57)
+  auto one = [&](uint32_t i) {
     const uint64_t bit = (uint64_t)i * w;
     const uint64_t byte = bit >> 3;
     uint64_t acc = 0;  // big-endian 40-bit window
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const uint64_t b = byte + k;
-      acc = (acc << 8) | (b < length ? (uint64_t)d.data[b] : 0ull);
+      acc = (acc << 8) | (b < length ? (uint64_t)data[b] : 0ull);
     }
     const uint32_t sh = 40u - ((uint32_t)bit & 7u) - w;
-    out[i] = (uint32_t)(acc >> sh) & mask;
+    return (uint32_t)(acc >> sh) & mask;
+  };
+  // four values per lane and step; widths up to 8 (levels): the four lie within eight bytes read at once
+  for (uint32_t i = threadIdx.x * 4u; i < n; i += 256u * 4u) {
+    const uint64_t bit = (uint64_t)i * w;
+    const uint64_t byte = bit >> 3;
+    if (w <= 8u && i + 4u <= n && byte + 8u <= length) {
+      uint64_t raw;
+      __builtin_memcpy(&raw, data + byte, 8);
+      const uint64_t be = __builtin_bswap64(raw);
+      const uint32_t sh = 64u - ((uint32_t)bit & 7u) - w;
+      const u32x4_a4 q = {(uint32_t)(be >> sh) & mask, (uint32_t)(be >> (sh - w)) & mask, (uint32_t)(be >> (sh - 2u * w)) & mask,
+                          (uint32_t)(be >> (sh - 3u * w)) & mask};
+      *(PQD_GLOBAL u32x4_a4*)(out + i) = q;
+    } else {
+      for (uint32_t k = 0; k < 4u && i + k < n; ++k) out[i + k] = one(i + k);
+    }
   }
   if (threadIdx.x == 0) {
     pqd_page_result r = {PQD_OK, n, (uint32_t)length, 0u};
