@@ -6,22 +6,30 @@
 // 27-35) and Lz4RawDecompressor.uncompress -> io.airlift.compress.lz4.Lz4Decompressor (codec/
 // Lz4RawDecompressor.java:29-49).  Both formats are a byte-serial stream of "copy these literal bytes" and
 // "repeat `length` bytes from `offset` back" elements, so a page is one serial chain; pages are
-// independent.  One wave per page: the element headers are decoded wave-uniformly (scalar registers), the
-// 64 lanes move the bytes.  The input is staged in LDS in 2 KiB chunks, the next chunk already on its way
-// in registers, and the headers are read from a 16-byte window of it kept in scalar registers; the last 32 KiB of output are kept in an LDS ring, which is where nearly every match
-// reads from (a match from further back reads the bytes back from memory).  Lane l of a match step takes
-// the byte `offset` back, or for offsets below 64 the byte (l mod offset) - offset back of the step's
-// start, which is the same byte of the repeating pattern and always already written.
-// Bound by the serial element chain, not by HBM: a wave spends several hundred cycles per element (scalar
-// decode, branches, one LDS round trip for the bytes), which is about 20 MB/s per page in flight, and LDS
-// holds four pages per CU.  (Buffering the output in the ring and writing it in 16-byte pieces, instead of
-// storing each element's bytes, was measured and is slower: the stores are not what the chain waits for.)
+// independent.  One wave per page.  Snappy is taken 64 input bytes at a time (snappy_window below: every byte
+// position is tried as an element header, the real chain is found by lane exchanges, literal bytes move in
+// one step, copies one after the other); LZ4 sequences, and Snappy streams in which something is out of
+// order, go element by element: the headers are decoded wave-uniformly (scalar registers, read from a
+// 16-byte window of the input kept there), the 64 lanes move the bytes.  The input is staged in LDS in 2 KiB
+// chunks, the next chunk already on its way in registers; the last 16 KiB of output are kept in an LDS ring,
+// which is where most matches read from; a match from further back reads the bytes back from L2.
+// Lane l of a match step takes the byte `offset` back, or for offsets below 64 the byte (l mod offset) -
+// offset back of the step's start, which is the same byte of the repeating pattern and always already
+// written.
+// Not HBM-bound: a page is a serial chain and a lone wave issues an instruction every ~17 cycles here
+// (branches, instruction fetch), about 20 MB/s per page; throughput is the number of pages in flight, which
+// LDS sets (20.5 KiB per page: seven per CU, 1792 per chip; 30 GB/s of text at that many pages).  Measured
+// and dropped: buffering the output in the ring and writing it in 16-byte pieces instead of storing each
+// element's bytes (slower: the stores are not what the chain waits for); a 32 KiB ring (fewer pages in
+// flight, and reading far matches back from L2 costs little once no system-wide fence is involved).
+#include <cstdlib>
+
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 
 namespace pqd {
 
-constexpr uint32_t LZ_RING = 32768;
+constexpr uint32_t LZ_RING_DEFAULT = 16384;  // PQD_LZ_RING=8|16|32 (KiB) chooses another size: more pages per CU against more matches read back from memory
 constexpr uint32_t LZ_CHUNK = 2048;
 constexpr uint32_t LZ_STAGE = 2 * LZ_CHUNK;
 
@@ -106,13 +114,15 @@ struct OutRing {
   uint8_t* ring;
   PQD_GLOBAL uint8_t* dst;
   uint32_t lane;
+  uint32_t ring_mask;  // ring bytes - 1
 
   // `len` literal bytes from the staged input (they lie within the staged chunks) or, long ones, from memory
-  __device__ __forceinline__ void literal(InStage& in, uint32_t from, uint32_t op, uint32_t len) {
-    if (len <= LZ_CHUNK - 16u) {
+  __device__ __forceinline__ void literal(InStage& in, uint32_t from, uint32_t op, uint32_t len,
+                                          uint32_t staged_limit = LZ_CHUNK - 16u) {
+    if (len <= staged_limit) {
       for (uint32_t i = lane; i < len; i += 64u) {
         const uint8_t v = (uint8_t)in.byte(from + i);
-        ring[(op + i) & (LZ_RING - 1u)] = v;
+        ring[(op + i) & ring_mask] = v;
         dst[op + i] = v;
       }
     } else {
@@ -120,7 +130,7 @@ struct OutRing {
 #pragma unroll 4
       for (uint32_t i = lane; i < len; i += 64u) {
         const uint8_t v = src[i];
-        ring[(op + i) & (LZ_RING - 1u)] = v;
+        ring[(op + i) & ring_mask] = v;
         dst[op + i] = v;
       }
     }
@@ -134,20 +144,23 @@ struct OutRing {
         lm = lm >= t ? lm - t : lm;
       }
     }
-    if (offset <= LZ_RING) {
+    if (offset <= ring_mask + 1u) {
       for (uint32_t b = 0; b < len; b += 64u) {
         if (b + lane < len) {
-          const uint8_t v = ring[(op + b + lm - offset) & (LZ_RING - 1u)];
-          ring[(op + b + lane) & (LZ_RING - 1u)] = v;
+          const uint8_t v = ring[(op + b + lm - offset) & ring_mask];
+          ring[(op + b + lane) & ring_mask] = v;
           dst[op + b + lane] = v;
         }
       }
     } else {
+      // The bytes were stored by this wave, long ago: its stores are waited for, and the loads read L2 (they
+      // pass the vector L1, which may hold an older copy of a line).  No wider fence: nobody else is involved.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       for (uint32_t b = 0; b < len; b += 64u) {
-        __threadfence();  // the bytes were stored by this wave: read them where the stores went
+        if (len > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a match that reads its own output
         if (b + lane < len) {
           const uint8_t v = __hip_atomic_load(dst + (op + b + lane - offset), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ring[(op + b + lane) & (LZ_RING - 1u)] = v;
+          ring[(op + b + lane) & ring_mask] = v;
           dst[op + b + lane] = v;
         }
       }
@@ -155,11 +168,123 @@ struct OutRing {
   }
 };
 
-template <int CODEC>
+// Snappy, 64 input bytes at a time.  Every lane reads the byte at ip + lane as if an element started there
+// (kind, header bytes, lengths, offset) and notes where the element after it would start.  Six rounds of
+// "and from there?" between the lanes give the 2^k-th successor of every position, from which lane i works
+// out the i-th element of the real chain that starts at ip: the elements of the window, in order, one per
+// lane.  A prefix sum of their output lengths places them; literal bytes are then moved by all lanes at
+// once (a lane per input byte), copies one after the other (they may read what the one before wrote), each
+// by the whole wave.  Returns false, with nothing done, when an element of the window breaks a rule
+// (offset 0 or beyond the output, bytes beyond the stream or the page): the caller then takes the
+// one-element-at-a-time path, which reports the failure the way the format's decoder does.
+constexpr uint32_t SW_BAD = 0xFFFFFFFFu, SW_END = 0xFFFFFFFEu;
+
+__device__ __forceinline__ bool snappy_window(InStage& in, OutRing& out, uint8_t* marks, uint32_t& ip, uint32_t& op,
+                                              uint32_t in_end, uint32_t cap, uint32_t lane) {
+  const uint32_t p = ip + lane;
+  const uint32_t* st32 = reinterpret_cast<const uint32_t*>(in.lds);
+  const uint32_t w0 = (p & (LZ_STAGE - 1u)) >> 2, sh = (p & 3u) * 8u;
+  const uint32_t d0 = st32[w0], d1 = st32[(w0 + 1u) & (LZ_STAGE / 4u - 1u)], d2 = st32[(w0 + 2u) & (LZ_STAGE / 4u - 1u)];
+  const uint32_t lo = funnel_shr(d0, d1, sh), hi = funnel_shr(d1, d2, sh);  // bytes p .. p+3, p+4 .. p+7
+  const uint32_t tag = lo & 0xFFu, kind = tag & 3u, n6 = tag >> 2;
+  const uint32_t rest = (lo >> 8) | (hi << 24);  // bytes p+1 .. p+4
+  // as a literal
+  const uint32_t nb = n6 >= 60u ? n6 - 59u : 0u;
+  const uint32_t lit_field = nb == 4u ? rest : rest & ((1u << (8u * nb)) - 1u);
+  const uint64_t lit_len = (uint64_t)(nb ? lit_field : n6) + 1u;
+  // as a copy
+  const uint32_t copy_hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
+  const uint32_t copy_len = kind == 1u ? 4u + (n6 & 7u) : 1u + n6;
+  const uint32_t offset = kind == 1u ? ((tag >> 5) << 8) | (rest & 0xFFu) : kind == 2u ? rest & 0xFFFFu : rest;
+  const bool is_lit = kind == 0u;
+  const uint32_t hdr = is_lit ? 1u + nb : copy_hdr;
+  const uint64_t adv64 = is_lit ? hdr + lit_len : hdr;
+  const bool fine = (uint64_t)p + adv64 <= in_end && (is_lit || offset != 0u) && lit_len < (1u << 28);  // (28 bits hold a length below)
+  const uint32_t adv = (uint32_t)adv64;
+  const uint32_t out_len = is_lit ? (uint32_t)lit_len : copy_len;
+  // successor, counted from the window's first byte (a value of 64 or more: outside the window)
+  uint32_t succ[6];
+  succ[0] = (p >= in_end || !fine) ? SW_BAD : p + adv == in_end ? SW_END : lane + adv;  // the stream's end is no position of the chain
+#pragma unroll
+  for (int k = 1; k < 6; ++k) {
+    const uint32_t further = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((succ[k - 1] & 63u) << 2), (int)succ[k - 1]);
+    succ[k] = succ[k - 1] < 64u ? further : succ[k - 1];
+  }
+  // lane i: the i-th element of the chain from position 0
+  uint32_t pos = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const uint32_t hop = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pos & 63u) << 2), (int)succ[k]);
+    if ((lane >> k) & 1u) pos = pos < 64u ? hop : pos;
+  }
+  const uint64_t inside = __builtin_amdgcn_ballot_w64(pos < 64u);  // lanes 0 .. T-1 (positions grow with i)
+  const uint32_t T = (uint32_t)__builtin_popcountll(inside);         // at most 32: an element is two bytes or more
+  const uint32_t leave = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)T);  // where the chain leaves the window
+  if (leave == SW_BAD) return false;
+  const bool mine = lane < T;
+  // the elements' fields, gathered from the lanes that parsed them
+  const uint32_t src_lane = (pos & 63u) << 2;
+  const uint32_t e_meta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane, (int)(out_len | (hdr << 28) | (is_lit ? 0x80000000u : 0u)));
+  const uint32_t e_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane, (int)offset);
+  const uint32_t e_out = mine ? e_meta & 0x0FFFFFFFu : 0u;  // (a literal of 2^28 bytes or more does not fit the stream: `fine` saw to it)
+  const bool e_lit = (e_meta >> 31) != 0;
+  const uint32_t inc = wave_scan_inclusive(e_out);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  const uint32_t e_op = op + inc - e_out;  // where the element's output starts
+  if ((uint64_t)op + total > cap) return false;
+  if (__builtin_amdgcn_ballot_w64(mine && !e_lit && e_off > e_op)) return false;
+  // ---- literal bytes, a lane per input byte: the element a byte belongs to is the last one that starts at
+  // or before it
+  __syncthreads();
+  marks[lane] = 0;
+  __syncthreads();
+  if (mine) marks[pos] = 1;
+  __syncthreads();
+  const uint64_t starts = __builtin_amdgcn_ballot_w64(marks[lane] != 0);
+  const uint32_t rank = (uint32_t)__builtin_popcountll(starts & ((2ull << lane) - 1ull)) - 1u;  // lane 0 starts an element
+  const uint32_t o_pos = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)pos);
+  const uint32_t o_meta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)e_meta);
+  const uint32_t o_op = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)e_op);
+  {
+    const uint32_t first = o_pos + ((o_meta >> 28) & 7u);  // the literal's first byte
+    if ((o_meta >> 31) && lane >= first && lane - first < (o_meta & 0x0FFFFFFFu)) {
+      const uint8_t v = (uint8_t)in.byte(p);
+      const uint32_t at = o_op + (lane - first);
+      out.ring[at & out.ring_mask] = v;
+      out.dst[at] = v;
+    }
+  }
+  // a literal that goes on behind the window: the rest of it
+  if (T) {
+    const uint32_t l_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(T - 1u));
+    const uint32_t l_meta = (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)(T - 1u));
+    const uint32_t l_op = (uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)(T - 1u));
+    const uint32_t first = l_pos + ((l_meta >> 28) & 7u), len = l_meta & 0x0FFFFFFFu;
+    if ((l_meta >> 31) && first + len > 64u) {
+      const uint32_t done = first < 64u ? 64u - first : 0u;       // bytes moved above
+      const uint32_t from = first < 64u ? 64u : first;            // window position of the next one
+      out.literal(in, ip + from, l_op + done, len - done, 1900u);  // (ip + 64 + 1900 lies inside the staged chunks)
+    }
+  }
+  // ---- copies, in order
+  uint64_t copies = __builtin_amdgcn_ballot_w64(mine && !e_lit);
+  while (copies) {
+    const uint32_t i = (uint32_t)__builtin_ctzll(copies);
+    copies &= copies - 1ull;
+    out.match((uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)i), (uint32_t)__builtin_amdgcn_readlane((int)e_off, (int)i),
+              (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)i) & 0x0FFFFFFFu);
+  }
+  op += total;
+  ip = leave == SW_END ? in_end : ip + leave;
+  return true;
+}
+
+template <int CODEC, uint32_t RING>
 __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
                                                  pqd_page_result* __restrict__ results, uint32_t n_pages) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[LZ_RING];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
+  __shared__ uint8_t s_marks[64];
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
@@ -182,7 +307,7 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
   in.start(0);
   in.win_at = 0x80000000u;  // nothing in the window yet
   in.win0 = in.win1 = 0;
-  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane};
+  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane, RING - 1u};
   const uint32_t cap = d.dst_len, in_end = in.end;
   uint32_t ip = skew, op = 0;
   int32_t status = PQD_OK;
@@ -206,8 +331,13 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
       status = PQD_DECODE;
       ip = skew;
     } else {
+      bool one_by_one = false;  // set when a window met something out of order: the rest of the page goes this way
       while (ip < in_end) {
         in.reach(ip);
+        if (!one_by_one) {
+          if (snappy_window(in, out, s_marks, ip, op, in_end, cap, lane)) continue;
+          one_by_one = true;
+        }
         const uint64_t head = in.peek8(ip);
         const uint32_t tag = (uint32_t)head & 0xFFu;
         const uint32_t rest = (uint32_t)(head >> 8);
@@ -347,13 +477,25 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
   }
 }
 
+template <uint32_t RING>
+static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
+  if (codec == PQD_CODEC_SNAPPY)
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  else if (codec == PQD_CODEC_LZ4_RAW)
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+}
+
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
                                    hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  if (codec == PQD_CODEC_SNAPPY)
-    hipLaunchKernelGGL(k_lz_pages<PQD_CODEC_SNAPPY>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
-  else if (codec == PQD_CODEC_LZ4_RAW)
-    hipLaunchKernelGGL(k_lz_pages<PQD_CODEC_LZ4_RAW>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  const char* v = getenv("PQD_LZ_RING");
+  const uint32_t ring = v ? (uint32_t)atoi(v) * 1024u : LZ_RING_DEFAULT;
+  if (ring == 8192u)
+    launch_lz<8192u>(descs, results, n_pages, codec, stream);
+  else if (ring == 32768u)
+    launch_lz<32768u>(descs, results, n_pages, codec, stream);
+  else
+    launch_lz<16384u>(descs, results, n_pages, codec, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages);

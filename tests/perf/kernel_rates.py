@@ -324,7 +324,7 @@ def decompression():
         return np.round(r.normal(size=size // 8), 2).astype("<f8").tobytes()
     for kind, make in (("text", text), ("int32 < 1000", ints), ("doubles, 2 decimals", doubles)):
         for codec, num in (("snappy", 1), ("lz4_raw", 7)):
-            n_p = 512
+            n_p = int(os.environ.get("KR_LZ_PAGES", "1792"))
             pages = distinct_pages(lambda r: pa.Codec(codec).compress(make(r), asbytes=True), n_p)
             offs = np.cumsum([0] + [p.size for p in pages])
             blob = torch.from_numpy(np.concatenate(pages + [np.zeros(64, np.uint8)])).to(DEV)
@@ -337,7 +337,7 @@ def decompression():
             t = timeit(lambda: pq.check(pq.lib.pqd_decompress_pages_dev(d_d.data_ptr(), res.data_ptr(), n_p, num, stream)), iters=3, warm=1)
             r = res.cpu().numpy().view(np.uint32).reshape(-1, 4)
             assert (r[:, 0] == 0).all() and (r[:, 1] == size).all()
-            report(f"{codec.upper()} pages of 1 MiB, {kind} (ratio {n_p * size / offs[-1]:.1f}), 512 pages", t, n_p * size, n_p * size,
+            report(f"{codec.upper()} pages of 1 MiB, {kind} (ratio {n_p * size / offs[-1]:.1f}), {n_p} pages", t, n_p * size, n_p * size,
                    int(offs[-1]) + n_p * size)
             del blob, out
 
