@@ -186,7 +186,8 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
  * HIP graph capture, serving loops that must not touch the allocator, harnesses that forbid it.
  * (No counterpart in the reference: the JVM allocates per run, RunLengthBitPackingHybridDecoder.java:94-99.)
  * Same arguments, same results, same kernels; the scratch of the planned hybrid / dictionary paths
- * (chunk pool, plan records, counters: 16 MiB + 16.25 KiB) lives in a device array that is part of
+ * (chunk pool 16 MiB, plan records 16 KiB, counters and slot table 6.25 KiB, eight dictionary plane slots
+ * 4 MiB: 20.02 MiB in all) lives in a device array that is part of
  * the library image, one copy per GPU, instead of buffers the library allocates.  It calls no
  * hipMalloc / hipFree.  Limits: at most 2048 pages per call (PQD_BAD_ARG beyond that; pages whose
  * runs outgrow the 8192-chunk pool are decoded by the generic kernel, as in pqd_decode_pages_dev).
