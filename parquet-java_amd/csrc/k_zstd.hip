@@ -1,0 +1,898 @@
+// Page decompression on the device: Zstandard frames.
+//
+// Replaces ZstdDecompressorStream (parquet-hadoop/.../hadoop/codec/ZstdDecompressorStream.java:30-60, a wrapper
+// of zstd-jni's ZstdInputStreamNoFinalizer, i.e. of the C library) as ColumnChunkPageReadStore calls it through
+// BytesInputDecompressor.decompress (ColumnChunkPageReadStore.java:151-181, :232-262).  The format is RFC 8878:
+// frames of raw / RLE / compressed blocks; a compressed block is a literals section (raw, RLE or
+// Huffman-coded in one or four streams) and a sequences section (FSE-coded literal-length / offset /
+// match-length codes read backwards from the block's end), executed as "copy `ll` literals, then `ml` bytes
+// from `offset` back".  No dictionaries (parquet pages carry none).
+// One wave per page.  The serial parts (headers, table descriptions, the sequence decode) run wave-uniformly:
+// every lane computes the same values from LDS, the 64 lanes together move the bytes.  The four Huffman
+// streams of a block are decoded by four lanes, each with its own bit reader, into the end of the page's
+// destination (a block's output never catches up with its unread literals there, because the block ends at
+// or before the page's end); they are then staged through LDS like the input.  Tables live in LDS for the
+// whole frame (repeat modes and treeless literals reuse them).
+// Latency-bound like the other codecs (a serial chain per page); throughput is the number of pages in flight.
+#include "pqd_device.hpp"
+#include "pqd_kernels.hpp"
+#include "pqd_lz_common.hpp"
+
+namespace pqd {
+
+constexpr uint32_t ZS_RING = 8192;
+constexpr uint32_t ZS_BLOCK_MAX = 128 * 1024;
+
+struct ZShared {
+  uint32_t ll[512], of[256], ml[512];  // FSE entries: symbol | bits << 8 | next-state base << 16
+  uint16_t huf[2048];                  // Huffman entries: symbol | bits << 8
+  int16_t norm[256];
+  uint16_t next[256];
+  uint8_t weights[256];
+  uint32_t wtab[64];                   // FSE table of the Huffman weights (accuracy log <= 6)
+  uint32_t log_ll, log_of, log_ml, have_ll, have_of, have_ml, huf_bits, huf_valid;
+  uint32_t rep[3];
+  int32_t lane_status[4];
+};
+
+__device__ const int16_t Z_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                             2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ const int16_t Z_ML_DEFAULT[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                             1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int16_t Z_OF_DEFAULT[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                             1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__device__ const uint32_t Z_LL_BASE[36] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,   10,  11,  12,   13,   14,   15,   16,    18,
+                                           20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__device__ const uint8_t Z_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                          1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const uint32_t Z_ML_BASE[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                           21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                           43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__device__ const uint8_t Z_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                          0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+__device__ __forceinline__ uint32_t zhighbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// a byte of the input (wave-uniform)
+__device__ __forceinline__ uint32_t zbyte(InStage& in, uint32_t pos) {
+  in.reach(pos);
+  return uni(in.byte(pos));
+}
+// up to 25 bits at bit `bit` of the input region that starts at `p0` and is `n` bytes long (zeros behind it)
+__device__ __forceinline__ uint32_t zfwd(InStage& in, uint32_t p0, uint32_t n, uint32_t bit, uint32_t k) {
+  uint64_t v = 0;
+  const uint32_t byte = bit >> 3;
+  for (uint32_t i = 0; i < 5; ++i)
+    if (byte + i < n) v |= (uint64_t)zbyte(in, p0 + byte + i) << (8 * i);
+  return (uint32_t)(v >> (bit & 7u)) & ((1u << k) - 1u);
+}
+// k <= 16 bits whose lowest is bit `lo` (may be negative: zeros) of the n-byte region at p0
+__device__ __forceinline__ uint32_t zback_small(InStage& in, uint32_t p0, uint32_t n, int32_t lo, uint32_t k) {
+  if (k == 0) return 0;
+  const int32_t b0 = lo >> 3;  // floor
+  uint32_t v = 0;
+  for (int32_t i = 0; i < 3; ++i) {
+    const int32_t b = b0 + i;
+    if (b >= 0 && b < (int32_t)n) v |= zbyte(in, p0 + (uint32_t)b) << (8 * i);
+  }
+  return (v >> ((uint32_t)lo & 7u)) & ((1u << k) - 1u);
+}
+
+// FSE decoding table from normalized counts (all lanes write the same entries)
+__device__ __forceinline__ bool zfse_build(uint32_t* tab, const int16_t* norm, uint16_t* next, uint32_t n_sym, uint32_t log) {
+  const uint32_t size = 1u << log;
+  int32_t high = (int32_t)size - 1;
+  for (uint32_t s = 0; s < n_sym; ++s) {
+    if (norm[s] == -1) {
+      tab[high--] = s;
+      next[s] = 1;
+    } else {
+      next[s] = (uint16_t)norm[s];
+    }
+  }
+  const uint32_t step = (size >> 1) + (size >> 3) + 3u, mask = size - 1u;
+  uint32_t pos = 0;
+  for (uint32_t s = 0; s < n_sym; ++s) {
+    for (int32_t i = 0; i < norm[s]; ++i) {
+      tab[pos] = s;
+      do pos = (pos + step) & mask;
+      while ((int32_t)pos > high);
+    }
+  }
+  if (pos != 0) return false;
+  __syncthreads();
+  for (uint32_t u = 0; u < size; ++u) {
+    const uint32_t s = tab[u] & 0xFFu;
+    const uint32_t ns = next[s];  // (the lanes of the wave run in step: all have read before any writes)
+    next[s] = (uint16_t)(ns + 1u);
+    const uint32_t nb = log - zhighbit(ns);
+    tab[u] = s | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16);
+  }
+  __syncthreads();
+  return true;
+}
+
+// normalized counts at input position p0 (n bytes available); returns bytes used or ~0u
+__device__ __forceinline__ uint32_t zfse_norm(InStage& in, uint32_t p0, uint32_t n, int16_t* norm, uint32_t& n_sym, uint32_t max_sym,
+                              uint32_t& log, uint32_t max_log) {
+  uint32_t bit = 0;
+  const uint32_t al = 5u + zfwd(in, p0, n, bit, 4);
+  bit += 4;
+  if (al > max_log) return ~0u;
+  int32_t remaining = (1 << al) + 1, threshold = 1 << al;
+  uint32_t nbits = al + 1, sym = 0;
+  bool prev0 = false;
+  while (remaining > 1 && sym <= max_sym) {
+    if (prev0) {
+      for (;;) {
+        const uint32_t rep = zfwd(in, p0, n, bit, 2);
+        bit += 2;
+        for (uint32_t i = 0; i < rep && sym <= max_sym; ++i) norm[sym++] = 0;
+        if (rep != 3) break;
+      }
+      if (sym > max_sym) break;
+    }
+    const int32_t max = (2 * threshold - 1) - remaining;
+    const uint32_t bits = zfwd(in, p0, n, bit, nbits);
+    int32_t count;
+    if ((int32_t)(bits & (uint32_t)(threshold - 1)) < max) {
+      count = (int32_t)(bits & (uint32_t)(threshold - 1));
+      bit += nbits - 1;
+    } else {
+      count = (int32_t)(bits & (uint32_t)(2 * threshold - 1));
+      if (count >= threshold) count -= max;
+      bit += nbits;
+    }
+    --count;
+    remaining -= count < 0 ? -count : count;
+    norm[sym++] = (int16_t)count;
+    prev0 = count == 0;
+    while (remaining < threshold) {
+      --nbits;
+      threshold >>= 1;
+    }
+    if (bit > n * 8u + 32u) return ~0u;
+  }
+  if (remaining != 1 || sym > max_sym + 1) return ~0u;
+  n_sym = sym;
+  log = al;
+  const uint32_t used = (bit + 7u) >> 3;
+  return used > n ? ~0u : used;
+}
+
+// Huffman table from the weights in sh.weights[0 .. n_given): false when they do not describe a tree
+__device__ __forceinline__ bool zhuf_build(ZShared& sh, uint32_t n_given) {
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < n_given; ++i) {
+    const uint32_t w = sh.weights[i];
+    if (w > 11) return false;
+    total += w ? 1u << (w - 1) : 0u;
+  }
+  if (total == 0) return false;
+  const uint32_t max_bits = zhighbit(total) + 1u;
+  if (max_bits > 11) return false;
+  const uint32_t rest = (1u << max_bits) - total;
+  if (rest & (rest - 1u)) return false;
+  sh.weights[n_given] = (uint8_t)(zhighbit(rest) + 1u);
+  __syncthreads();
+  const uint32_t n = n_given + 1;
+  uint32_t start[13], cnt[13];
+  for (int r = 0; r < 13; ++r) start[r] = cnt[r] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t w = sh.weights[i];
+    for (int r = 0; r < 13; ++r) cnt[r] += (uint32_t)r == w ? 1u : 0u;
+  }
+  uint32_t at = 0;
+  for (uint32_t r = 1; r <= max_bits; ++r) {
+    start[r] = at;
+    at += cnt[r] << (r - 1);
+  }
+  if (at != (1u << max_bits)) return false;
+  // symbols of one weight lie one behind the other in symbol order; the 64 lanes fill an entry range together
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t s = 0; s < n; ++s) {
+    const uint32_t w = sh.weights[s];
+    if (!w) continue;
+    const uint32_t len = 1u << (w - 1);
+    uint32_t first = 0;
+    for (int r = 0; r < 13; ++r) first = (uint32_t)r == w ? start[r] : first;
+    const uint16_t e = (uint16_t)(s | ((max_bits + 1u - w) << 8));
+    for (uint32_t i = lane; i < len; i += 64u) sh.huf[first + i] = e;
+    for (int r = 0; r < 13; ++r) start[r] += (uint32_t)r == w ? len : 0u;
+  }
+  sh.huf_bits = max_bits;
+  sh.huf_valid = 1;
+  __syncthreads();
+  return true;
+}
+
+// Huffman tree description at input position p0 (n bytes available); returns bytes used or ~0u
+__device__ __forceinline__ uint32_t zhuf_tree(ZShared& sh, InStage& in, uint32_t p0, uint32_t n) {
+  if (n == 0) return ~0u;
+  const uint32_t hb = zbyte(in, p0);
+  uint32_t n_w = 0, used;
+  if (hb >= 128) {
+    n_w = hb - 127;
+    used = 1 + (n_w + 1) / 2;
+    if (used > n) return ~0u;
+    for (uint32_t i = 0; i < n_w; ++i) {
+      const uint32_t b = zbyte(in, p0 + 1 + i / 2);
+      sh.weights[i] = (uint8_t)((i & 1u) ? b & 15u : b >> 4);
+    }
+  } else {
+    used = 1 + hb;
+    if (used > n || hb == 0) return ~0u;
+    uint32_t n_sym, log;
+    const uint32_t tb = zfse_norm(in, p0 + 1, hb, sh.norm, n_sym, 255, log, 6);
+    if (tb == ~0u) return ~0u;
+    __syncthreads();
+    if (!zfse_build(sh.wtab, sh.norm, sh.next, n_sym, log)) return ~0u;
+    const uint32_t sp = p0 + 1 + tb, sn = hb - tb;
+    if (sn == 0) return ~0u;
+    const uint32_t last = zbyte(in, sp + sn - 1);
+    if (last == 0) return ~0u;
+    int32_t bit = (int32_t)(sn - 1) * 8 + (int32_t)zhighbit(last);
+    bit -= (int32_t)log;
+    uint32_t s1 = zback_small(in, sp, sn, bit, log);
+    bit -= (int32_t)log;
+    uint32_t s2 = zback_small(in, sp, sn, bit, log);
+    for (;;) {
+      if (n_w >= 254) return ~0u;
+      uint32_t e1 = sh.wtab[s1], e2 = sh.wtab[s2];
+      sh.weights[n_w++] = (uint8_t)e1;
+      uint32_t nb = (e1 >> 8) & 0xFFu;
+      if (bit < (int32_t)nb) {
+        if (n_w >= 255) return ~0u;
+        sh.weights[n_w++] = (uint8_t)e2;
+        break;
+      }
+      bit -= (int32_t)nb;
+      s1 = (e1 >> 16) + zback_small(in, sp, sn, bit, nb);
+      sh.weights[n_w++] = (uint8_t)e2;
+      nb = (e2 >> 8) & 0xFFu;
+      if (bit < (int32_t)nb) {
+        if (n_w >= 255) return ~0u;
+        sh.weights[n_w++] = (uint8_t)sh.wtab[s1];
+        break;
+      }
+      bit -= (int32_t)nb;
+      s2 = (e2 >> 16) + zback_small(in, sp, sn, bit, nb);
+    }
+  }
+  __syncthreads();
+  if (!zhuf_build(sh, n_w)) return ~0u;
+  return used;
+}
+
+// One Huffman stream by one lane: `count` symbols from the n bytes at `p` to `out`; PQD_OK when the stream is
+// used up exactly.  (Reads 8 bytes at a time from memory; a read in front of the stream supplies zeros.)
+__device__ __forceinline__ int32_t zhuf_stream(const ZShared& sh, const PQD_GLOBAL uint8_t* p, uint32_t n, PQD_GLOBAL uint8_t* out, uint32_t count) {
+  if (n == 0 || p[n - 1] == 0) return PQD_DECODE;
+  int64_t bit = (int64_t)(n - 1) * 8 + (int64_t)zhighbit(p[n - 1]);
+  const uint32_t mb = sh.huf_bits;
+  uint64_t cache = 0;
+  int64_t cache_lo = bit + 1;  // nothing cached
+  for (uint32_t i = 0; i < count; ++i) {
+    const int64_t lo = bit - (int64_t)mb;  // lowest bit of the peeked field
+    if (lo < cache_lo) {
+      // 64 bits from a byte boundary, ending at or just above the field's top: at least 46 bits of fields per fill
+      const int64_t byte0 = (lo + (int64_t)mb - 64 + 7) >> 3;  // floor
+      cache_lo = byte0 * 8;
+      if (byte0 >= 0 && byte0 + 8 <= (int64_t)n) {
+        __builtin_memcpy(&cache, p + byte0, 8);
+      } else {
+        cache = 0;
+        for (int k = 0; k < 8; ++k) {
+          const int64_t q = byte0 + k;
+          if (q >= 0 && q < (int64_t)n) cache |= (uint64_t)p[q] << (8 * k);
+        }
+      }
+    }
+    const uint32_t v = (uint32_t)(cache >> (lo - cache_lo)) & ((1u << mb) - 1u);
+    const uint32_t e = sh.huf[v];
+    out[i] = (uint8_t)e;
+    bit -= (int64_t)(e >> 8);
+  }
+  return bit == 0 ? PQD_OK : PQD_DECODE;
+}
+
+// The sequences' bit stream, read backwards: the region [p0, p0 + n) of the input is staged 4 KiB at a time in
+// LDS; 64 bits are fetched at once and fields taken from them.
+struct BackBits {
+  const PQD_GLOBAL uint8_t* base;  // input base (16-byte aligned); positions count from it
+  uint32_t p0, n;
+  uint8_t* lds;
+  int64_t bit;       // bits not yet read
+  int32_t win_chunk;  // chunks win_chunk and win_chunk + 1 of the region are staged (chunk = 2 KiB of the region); INT_MIN: none
+  uint64_t cache;
+  int64_t cache_lo;
+  uint32_t lane;
+
+  __device__ __forceinline__ void stage(int32_t c) {
+    __syncthreads();
+    for (uint32_t k = 0; k < 4; ++k) {
+      const int64_t rpos = (int64_t)c * LZ_CHUNK + (int64_t)(k * 1024u + lane * 16u);  // region position of this lane's 16 bytes
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (rpos >= 0 && rpos + 16 <= (int64_t)n) {
+        __builtin_memcpy(&v, base + p0 + (uint32_t)rpos, 16);
+      } else if (rpos + 16 > 0 && rpos < (int64_t)n) {
+        uint32_t tmp[4] = {0u, 0u, 0u, 0u};
+        for (int b = 0; b < 16; ++b) {
+          const int64_t q = rpos + b;
+          if (q >= 0 && q < (int64_t)n) tmp[b >> 2] |= (uint32_t)base[p0 + (uint32_t)q] << (8 * (b & 3));
+        }
+        v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+      }
+      *reinterpret_cast<u32x4*>(lds + k * 1024u + lane * 16u) = v;
+    }
+    win_chunk = c;
+    __syncthreads();
+  }
+  // 64 bits whose lowest is region bit 8 * byte0 (byte0 may be negative)
+  __device__ __forceinline__ uint64_t fetch(int64_t byte0) {
+    const int32_t c = (int32_t)((byte0 + 7) >> 11) - 1;  // the 8 bytes lie in chunks c, c + 1
+    if (c != win_chunk) stage(c);
+    const uint32_t off = (uint32_t)(byte0 - (int64_t)c * LZ_CHUNK);  // 0 .. 4088
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
+    const uint32_t i0 = off >> 2, sh = (off & 3u) * 8u;
+    const uint32_t d0 = uni(w[i0]), d1 = uni(w[i0 + 1]), d2 = uni(w[(i0 + 2) & (LZ_STAGE / 4 - 1)]);
+    const uint32_t lo = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0, hi = sh ? (d1 >> sh) | (d2 << (32u - sh)) : d1;
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ uint32_t read(uint32_t k) {  // k <= 32
+    if (k == 0) return 0;
+    bit -= (int64_t)k;
+    if (bit < cache_lo) {
+      const int64_t byte0 = (bit + (int64_t)k - 64 + 7) >> 3;  // the cache ends at or above the field's top
+      cache_lo = byte0 * 8;
+      cache = fetch(byte0);
+    }
+    return (uint32_t)(cache >> (bit - cache_lo)) & (k == 32 ? 0xFFFFFFFFu : (1u << k) - 1u);
+  }
+};
+
+// one table of the sequences section; returns bytes used or ~0u
+__device__ __forceinline__ uint32_t zseq_table(ZShared& sh, InStage& in, uint32_t* tab, uint32_t& tlog, uint32_t& have, uint32_t mode, uint32_t p0,
+                               uint32_t n, const PQD_GLOBAL int16_t* def, uint32_t def_n, uint32_t def_log, uint32_t max_sym, uint32_t max_log) {
+  if (mode == 3) return have ? 0u : ~0u;  // repeat
+  if (mode == 1) {  // one symbol, no bits
+    if (n < 1) return ~0u;
+    const uint32_t s = zbyte(in, p0);
+    if (s > max_sym) return ~0u;
+    tab[0] = s;
+    tlog = 0;
+    have = 1;
+    __syncthreads();
+    return 1;
+  }
+  uint32_t n_sym = def_n, log = def_log, used = 0;
+  if (mode == 0) {
+    for (uint32_t i = 0; i < def_n; ++i) sh.norm[i] = def[i];
+  } else {
+    used = zfse_norm(in, p0, n, sh.norm, n_sym, max_sym, log, max_log);
+    if (used == ~0u) return ~0u;
+  }
+  __syncthreads();
+  if (!zfse_build(tab, sh.norm, sh.next, n_sym, log)) return ~0u;
+  tlog = log;
+  have = 1;
+  return used;
+
+}
+
+// XXH64 of n bytes this wave stored at p (the frame's content checksum is its low 32 bits): the four
+// accumulators run in four lanes, the rest is computed by every lane alike.
+__device__ __forceinline__ uint64_t zxxh64(const PQD_GLOBAL uint8_t* p, uint32_t n, uint32_t lane) {
+  constexpr uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull,
+                     P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+  auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+  auto round1 = [&](uint64_t acc, uint64_t v) { return rotl(acc + v * P2, 31) * P1; };
+  auto rd = [&](uint32_t at, uint32_t k) {  // k bytes, little endian
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < k; ++i) v |= (uint64_t)p[at + i] << (8 * i);
+    return v;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  uint32_t at = 0;
+  uint64_t h;
+  if (n >= 32u) {
+    const uint32_t q = lane & 3u;
+    uint64_t v = q == 0 ? P1 + P2 : q == 1 ? P2 : q == 2 ? 0ull : 0ull - P1;
+    const uint32_t stripes = n / 32u;
+    for (uint32_t s = 0; s < stripes; ++s) {
+      uint64_t w;
+      __builtin_memcpy(&w, p + (size_t)s * 32u + q * 8u, 8);
+      v = round1(v, w);
+    }
+    at = stripes * 32u;
+    uint64_t acc[4];
+    for (int k = 0; k < 4; ++k)
+      acc[k] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k);
+    h = rotl(acc[0], 1) + rotl(acc[1], 7) + rotl(acc[2], 12) + rotl(acc[3], 18);
+    for (int k = 0; k < 4; ++k) h = (h ^ round1(0, acc[k])) * P1 + P4;
+  } else {
+    h = P5;
+  }
+  h += (uint64_t)n;
+  for (; at + 8u <= n; at += 8u) {
+    h ^= round1(0, rd(at, 8));
+    h = rotl(h, 27) * P1 + P4;
+  }
+  if (at + 4u <= n) {
+    h ^= rd(at, 4) * P1;
+    h = rotl(h, 23) * P2 + P3;
+    at += 4u;
+  }
+  for (; at < n; ++at) {
+    h ^= rd(at, 1) * P5;
+    h = rotl(h, 11) * P1;
+  }
+  h ^= h >> 33;
+  h *= P2;
+  h ^= h >> 29;
+  h *= P3;
+  h ^= h >> 32;
+  return h;
+}
+
+__global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __restrict__ descs,
+                                                   pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  __shared__ ZShared sh;
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZS_RING];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lits[LZ_STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_back[LZ_STAGE];
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_decompress_desc d = descs[page];
+  if (d.codec != (uint32_t)PQD_CODEC_ZSTD) return;  // another kernel's page
+  const uint32_t lane = threadIdx.x;
+  if (d.src_len > 0x7fffffffu) {
+    if (lane == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  InStage in;
+  in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
+  const uint32_t skew = (uint32_t)((uintptr_t)d.src & 15u);
+  in.end = skew + d.src_len;
+  in.lane = lane;
+  in.lds = s_stage;
+  in.cur = 0;
+  in.start(0);
+  in.win_at = 0x80000000u;
+  in.win0 = in.win1 = 0;
+  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane, ZS_RING - 1u};
+  PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)d.dst;
+  const uint32_t cap = d.dst_len, in_end = in.end;
+  uint32_t ip = skew, op = 0;
+  int32_t status = PQD_OK;
+
+  while (ip < in_end && status == PQD_OK) {  // frames one behind the other
+    if (in_end - ip < 4u) {
+      status = PQD_DECODE;
+      break;
+    }
+    const uint32_t magic = zbyte(in, ip) | (zbyte(in, ip + 1) << 8) | (zbyte(in, ip + 2) << 16) | (zbyte(in, ip + 3) << 24);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame
+      if (in_end - ip < 8u) {
+        status = PQD_DECODE;
+        break;
+      }
+      const uint32_t sz = zbyte(in, ip + 4) | (zbyte(in, ip + 5) << 8) | (zbyte(in, ip + 6) << 16) | (zbyte(in, ip + 7) << 24);
+      if (in_end - ip - 8u < sz) {
+        status = PQD_DECODE;
+        break;
+      }
+      ip += 8u + sz;
+      continue;
+    }
+    if (magic != 0xFD2FB528u || in_end - ip < 5u) {
+      status = PQD_DECODE;
+      break;
+    }
+    const uint32_t fhd = zbyte(in, ip + 4);
+    uint32_t p = ip + 5;
+    const uint32_t single = (fhd >> 5) & 1u, checksum = (fhd >> 2) & 1u, did = fhd & 3u, fcs = fhd >> 6;
+    if (fhd & 0x08u) {
+      status = PQD_DECODE;
+      break;
+    }
+    const uint32_t did_bytes = did == 3u ? 4u : did, fcs_bytes = fcs == 0u ? single : 1u << fcs;
+    if (in_end - p < (single ? 0u : 1u) + did_bytes + fcs_bytes) {
+      status = PQD_DECODE;
+      break;
+    }
+    if (!single) ++p;  // window size: no limit is enforced
+    uint32_t dict_id = 0;
+    for (uint32_t i = 0; i < did_bytes; ++i) dict_id |= zbyte(in, p++) << (8 * i);
+    if (dict_id != 0) {  // a dictionary is needed
+      status = PQD_DECODE;
+      break;
+    }
+    uint64_t content = 0;
+    for (uint32_t i = 0; i < fcs_bytes; ++i) content |= (uint64_t)zbyte(in, p++) << (8 * i);
+    if (fcs_bytes == 2) content += 256;
+    __syncthreads();
+    sh.have_ll = sh.have_of = sh.have_ml = sh.huf_valid = 0;
+    sh.rep[0] = 1;
+    sh.rep[1] = 4;
+    sh.rep[2] = 8;
+    __syncthreads();
+    const uint32_t frame_start = op;
+    for (;;) {  // blocks
+      if (in_end - p < 3u) {
+        status = PQD_DECODE;
+        break;
+      }
+      const uint32_t bh = zbyte(in, p) | (zbyte(in, p + 1) << 8) | (zbyte(in, p + 2) << 16);
+      p += 3;
+      const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, size = bh >> 3;
+      if (type == 0) {  // raw
+        if (in_end - p < size || size > cap - op) {
+          status = PQD_DECODE;
+          break;
+        }
+        for (uint32_t done = 0; done < size;) {
+          const uint32_t nn = size - done < 1900u ? size - done : 1900u;
+          in.reach(p + done);
+          out.literal(in, p + done, op + done, nn, 1900u);
+          done += nn;
+        }
+        op += size;
+        p += size;
+      } else if (type == 1) {  // one byte, repeated
+        if (in_end - p < 1u || size > cap - op) {
+          status = PQD_DECODE;
+          break;
+        }
+        const uint8_t v = (uint8_t)zbyte(in, p);
+        for (uint32_t i = lane; i < size; i += 64u) {
+          s_ring[(op + i) & (ZS_RING - 1u)] = v;
+          dst[op + i] = v;
+        }
+        op += size;
+        p += 1;
+      } else if (type == 2) {
+        if (in_end - p < size || size > ZS_BLOCK_MAX || size < 1u) {
+          status = PQD_DECODE;
+          break;
+        }
+        // ---- literals
+        const uint32_t b0 = zbyte(in, p);
+        const uint32_t lt = b0 & 3u, sf = (b0 >> 2) & 3u;
+        uint32_t hdr, regen, comp = 0, streams = 1;
+        if (lt < 2) {
+          if (sf == 0 || sf == 2) {
+            hdr = 1;
+            regen = b0 >> 3;
+          } else if (sf == 1) {
+            hdr = 2;
+            if (size < 2) {
+              status = PQD_DECODE;
+              break;
+            }
+            regen = (b0 >> 4) | (zbyte(in, p + 1) << 4);
+          } else {
+            hdr = 3;
+            if (size < 3) {
+              status = PQD_DECODE;
+              break;
+            }
+            regen = (b0 >> 4) | (zbyte(in, p + 1) << 4) | (zbyte(in, p + 2) << 12);
+          }
+        } else {
+          const uint32_t bits = sf < 2 ? 10u : sf == 2 ? 14u : 18u;
+          hdr = sf < 2 ? 3u : sf == 2 ? 4u : 5u;
+          streams = sf == 0 ? 1u : 4u;
+          if (size < hdr) {
+            status = PQD_DECODE;
+            break;
+          }
+          uint64_t h = 0;
+          for (uint32_t i = 0; i < hdr; ++i) h |= (uint64_t)zbyte(in, p + i) << (8 * i);
+          regen = (uint32_t)(h >> 4) & ((1u << bits) - 1u);
+          comp = (uint32_t)(h >> (4 + bits)) & ((1u << bits) - 1u);
+        }
+        if (regen > ZS_BLOCK_MAX) {
+          status = PQD_DECODE;
+          break;
+        }
+        uint32_t pos = hdr;  // within the block
+        // where the literals are read from: the input (raw), one byte (RLE), or the page's end (Huffman)
+        InStage lits;
+        lits.lane = lane;
+        lits.lds = s_lits;
+        lits.cur = 0;
+        lits.win_at = 0x80000000u;
+        lits.win0 = lits.win1 = 0;
+        uint32_t lit_pos = 0;  // position of the next literal in `lits` coordinates
+        uint32_t rle_byte = 0;
+        if (lt == 0) {
+          if (size - pos < regen) {
+            status = PQD_DECODE;
+            break;
+          }
+          lits.base = in.base;
+          lits.end = in.end;
+          lit_pos = p + pos;
+          pos += regen;
+        } else if (lt == 1) {
+          if (size - pos < 1u) {
+            status = PQD_DECODE;
+            break;
+          }
+          rle_byte = zbyte(in, p + pos);
+          pos += 1;
+        } else {
+          if (size - pos < comp) {
+            status = PQD_DECODE;
+            break;
+          }
+          uint32_t q = p + pos, left = comp;
+          if (lt == 2) {
+            const uint32_t used = zhuf_tree(sh, in, q, left);
+            if (used == ~0u) {
+              status = PQD_DECODE;
+              break;
+            }
+            q += used;
+            left -= used;
+          } else if (!sh.huf_valid) {
+            status = PQD_DECODE;
+            break;
+          }
+          // the literals are decoded into the last `regen` bytes of the destination (when the page has room for
+          // them at all: a block cannot hold more literals than the page has bytes left)
+          if (regen > cap - op) {
+            status = PQD_DECODE;
+            break;
+          }
+          PQD_GLOBAL uint8_t* lit_out = dst + (cap - regen);
+          const PQD_GLOBAL uint8_t* sbase = in.base + q;
+          int32_t hst = PQD_OK;
+          if (streams == 1) {
+            if (lane == 0) sh.lane_status[0] = zhuf_stream(sh, sbase, left, lit_out, regen);
+            __syncthreads();
+            hst = sh.lane_status[0];
+          } else {
+            if (left < 6u) {
+              status = PQD_DECODE;
+              break;
+            }
+            const uint32_t s1 = zbyte(in, q) | (zbyte(in, q + 1) << 8), s2 = zbyte(in, q + 2) | (zbyte(in, q + 3) << 8),
+                           s3 = zbyte(in, q + 4) | (zbyte(in, q + 5) << 8);
+            const uint32_t each = (regen + 3u) / 4u;
+            if (6u + s1 + s2 + s3 > left || each * 3u > regen) {
+              status = PQD_DECODE;
+              break;
+            }
+            const uint32_t s4 = left - 6u - s1 - s2 - s3;
+            if (lane < 4) {
+              const uint32_t off = lane == 0 ? 0u : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
+              const uint32_t len = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : s4;
+              const uint32_t cnt = lane < 3 ? each : regen - 3u * each;
+              sh.lane_status[lane] = zhuf_stream(sh, sbase + 6u + off, len, lit_out + lane * each, cnt);
+            }
+            __syncthreads();
+            // the first stream that fails decides (the streams are decoded in order by the format's decoder)
+            for (int k = 3; k >= 0; --k) hst = sh.lane_status[k] != PQD_OK ? sh.lane_status[k] : hst;
+          }
+          if (hst != PQD_OK) {
+            status = hst;
+            break;
+          }
+          pos += comp;
+          // the decoded literals: stored by lanes of this wave, read back through memory
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          lits.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)lit_out & ~(uintptr_t)15);
+          lit_pos = (uint32_t)((uintptr_t)lit_out & 15u);
+          lits.end = lit_pos + regen;
+        }
+        if (lt != 1) lits.start(lit_pos / LZ_CHUNK);
+        uint32_t lit_left = regen;
+        // copies `n` literals to the output
+        auto put_literals = [&](uint32_t n) {
+          if (lt == 1) {
+            for (uint32_t i = lane; i < n; i += 64u) {
+              s_ring[(op + i) & (ZS_RING - 1u)] = (uint8_t)rle_byte;
+              dst[op + i] = (uint8_t)rle_byte;
+            }
+          } else {
+            for (uint32_t done = 0; done < n;) {
+              const uint32_t nn = n - done < 1900u ? n - done : 1900u;
+              lits.reach(lit_pos + done);
+              out.literal(lits, lit_pos + done, op + done, nn, 1900u);
+              done += nn;
+            }
+          }
+          lit_pos += n;
+          lit_left -= n;
+          op += n;
+        };
+        // ---- sequences
+        if (size - pos < 1u) {
+          status = PQD_DECODE;
+          break;
+        }
+        uint32_t n_seq = zbyte(in, p + pos);
+        pos += 1;
+        if (n_seq >= 128u) {
+          if (n_seq == 255u) {
+            if (size - pos < 2u) {
+              status = PQD_DECODE;
+              break;
+            }
+            n_seq = zbyte(in, p + pos) + (zbyte(in, p + pos + 1) << 8) + 0x7F00u;
+            pos += 2;
+          } else {
+            if (size - pos < 1u) {
+              status = PQD_DECODE;
+              break;
+            }
+            n_seq = ((n_seq - 128u) << 8) + zbyte(in, p + pos);
+            pos += 1;
+          }
+        }
+        if (n_seq) {
+          if (size - pos < 1u) {
+            status = PQD_DECODE;
+            break;
+          }
+          const uint32_t modes = zbyte(in, p + pos);
+          pos += 1;
+          if (modes & 3u) {
+            status = PQD_DECODE;
+            break;
+          }
+          uint32_t used = 0;
+          for (uint32_t t = 0; t < 3u && used != ~0u; ++t) {  // literal lengths, offsets, match lengths
+            uint32_t* tab = t == 0 ? sh.ll : t == 1 ? sh.of : sh.ml;
+            uint32_t& tlog = t == 0 ? sh.log_ll : t == 1 ? sh.log_of : sh.log_ml;
+            uint32_t& have = t == 0 ? sh.have_ll : t == 1 ? sh.have_of : sh.have_ml;
+            const PQD_GLOBAL int16_t* def = (const PQD_GLOBAL int16_t*)(t == 0 ? Z_LL_DEFAULT : t == 1 ? Z_OF_DEFAULT : Z_ML_DEFAULT);
+            used = zseq_table(sh, in, tab, tlog, have, (modes >> (6u - 2u * t)) & 3u, p + pos, size - pos, def,
+                              t == 0 ? 36u : t == 1 ? 29u : 53u, t == 1 ? 5u : 6u, t == 0 ? 35u : t == 1 ? 31u : 52u, t == 1 ? 8u : 9u);
+            if (used != ~0u) pos += used;
+          }
+          if (used == ~0u) {
+            status = PQD_DECODE;
+            break;
+          }
+          __syncthreads();
+          const uint32_t sn = size - pos;
+          if (sn == 0) {
+            status = PQD_DECODE;
+            break;
+          }
+          const uint32_t last_byte = zbyte(in, p + size - 1);
+          if (last_byte == 0) {
+            status = PQD_DECODE;
+            break;
+          }
+          BackBits bb;
+          bb.base = in.base;
+          bb.p0 = p + pos;
+          bb.n = sn;
+          bb.lds = s_back;
+          bb.lane = lane;
+          bb.win_chunk = (int32_t)0x80000000;
+          bb.bit = (int64_t)(sn - 1) * 8 + (int64_t)zhighbit(last_byte);
+          bb.cache = 0;
+          bb.cache_lo = bb.bit + 1;
+          const uint32_t log_ll = uni(sh.log_ll), log_of = uni(sh.log_of), log_ml = uni(sh.log_ml);
+          uint32_t sl = bb.read(log_ll), so = bb.read(log_of), sm = bb.read(log_ml);
+          uint32_t rep0 = uni(sh.rep[0]), rep1 = uni(sh.rep[1]), rep2 = uni(sh.rep[2]);
+          for (uint32_t i = 0; i < n_seq; ++i) {
+            const uint32_t eo = uni(sh.of[so]), em = uni(sh.ml[sm]), el = uni(sh.ll[sl]);
+            const uint32_t oc = eo & 0xFFu, mc = em & 0xFFu, lc = el & 0xFFu;
+            if (oc > 31u || mc > 52u || lc > 35u) {
+              status = PQD_DECODE;
+              break;
+            }
+            const uint64_t ov = (1ull << oc) + bb.read(oc);
+            const uint32_t ml = Z_ML_BASE[mc] + bb.read(Z_ML_BITS[mc]);
+            const uint32_t ll = Z_LL_BASE[lc] + bb.read(Z_LL_BITS[lc]);
+            if (i + 1 < n_seq) {
+              sl = (el >> 16) + bb.read((el >> 8) & 0xFFu);
+              sm = (em >> 16) + bb.read((em >> 8) & 0xFFu);
+              so = (eo >> 16) + bb.read((eo >> 8) & 0xFFu);
+            }
+            if (bb.bit < 0) {
+              status = PQD_DECODE;
+              break;
+            }
+            uint32_t offset;
+            if (ov > 3u) {
+              offset = (uint32_t)(ov - 3u);
+              rep2 = rep1;
+              rep1 = rep0;
+              rep0 = offset;
+            } else {
+              const uint32_t idx = (uint32_t)ov - 1u + (ll == 0 ? 1u : 0u);
+              if (idx == 0) {
+                offset = rep0;
+              } else {
+                offset = idx == 3 ? rep0 - 1u : idx == 1 ? rep1 : rep2;
+                if (idx > 1) rep2 = rep1;
+                rep1 = rep0;
+                rep0 = offset;
+              }
+            }
+            if (ll > lit_left || ll > cap - op) {
+              status = PQD_DECODE;
+              break;
+            }
+            put_literals(ll);
+            // matches reach back into the frame only
+            if (offset == 0u || offset > op - frame_start || ml > cap - op) {
+              status = PQD_DECODE;
+              break;
+            }
+            out.match(op, offset, ml);
+            op += ml;
+          }
+          __syncthreads();
+          sh.rep[0] = rep0;
+          sh.rep[1] = rep1;
+          sh.rep[2] = rep2;
+          __syncthreads();
+          if (status != PQD_OK) break;
+          if (bb.bit != 0) {
+            status = PQD_DECODE;
+            break;
+          }
+        } else if (pos != size) {
+          status = PQD_DECODE;
+          break;
+        }
+        if (lit_left > cap - op) {
+          status = PQD_DECODE;
+          break;
+        }
+        put_literals(lit_left);
+        p += size;
+      } else {
+        status = PQD_DECODE;
+        break;
+      }
+      if (last) break;
+    }
+    if (status != PQD_OK) break;
+    if (fcs_bytes != 0 && content != (uint64_t)(op - frame_start)) {
+      status = PQD_DECODE;
+      break;
+    }
+    if (checksum) {
+      if (in_end - p < 4u) {
+        status = PQD_DECODE;
+        break;
+      }
+      const uint32_t want = zbyte(in, p) | (zbyte(in, p + 1) << 8) | (zbyte(in, p + 2) << 16) | (zbyte(in, p + 3) << 24);
+      if (uni((uint32_t)zxxh64(dst + frame_start, op - frame_start, lane)) != want) {
+        status = PQD_DECODE;
+        break;
+      }
+      p += 4;
+    }
+    ip = p;
+  }
+  if (status == PQD_OK && op != cap) status = PQD_DECODE;  // the page header announced cap bytes
+  if (lane == 0) {
+    pqd_page_result r = {status, op, ip - skew, 0u};
+    results[page] = r;
+  }
+}
+
+hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_zstd_pages, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  return hipGetLastError();
+}
+
+}  // namespace pqd

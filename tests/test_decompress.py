@@ -1,8 +1,9 @@
-"""Page decompression (SNAPPY, LZ4_RAW).  The algorithms live in third-party libraries the reference calls
-(snappy-java 1.1.10.8, aircompressor 2.0.3); the oracle restates the published formats (oracle/
-pqd_oracle_pages.c) and is pinned by byte strings and parquet pages compressed with the C libraries of the
-same formats through pyarrow (tests/golden/codec_vectors.json, pyarrow_chunks.json) and by hand-made streams
-that use every element type; the HIP kernels are checked against the oracle on all of these and on damaged
+"""Page decompression (SNAPPY, LZ4_RAW, ZSTD).  The algorithms live in third-party libraries the reference
+calls (snappy-java 1.1.10.8, aircompressor 2.0.3, zstd-jni 1.5.7-13); the oracle restates the published formats
+(oracle/pqd_oracle_pages.c, pqd_oracle_zstd.c) and is pinned by byte strings and parquet pages compressed with
+the C libraries of the same formats through pyarrow (tests/golden/codec_vectors.json, pyarrow_chunks.json) and
+by hand-made streams that use every element type; the HIP kernels are checked against the oracle on all of
+these, on streams compressed when the test runs (large inputs, several compression levels) and on damaged
 streams."""
 import base64
 import hashlib
@@ -17,10 +18,26 @@ import pagefile as pf
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "codec_vectors.json")) as f:
-    VECTORS = [v for v in json.load(f)["vectors"] if v["codec"] in ("SNAPPY", "LZ4_RAW")]
-ORIGINALS = dict(codec_inputs.inputs())
-CODEC_NUM = {"SNAPPY": 1, "LZ4_RAW": 7, "UNCOMPRESSED": 0}
-PAGES = [fx for fx in pf.load_fixtures() if fx["codec"] in ("SNAPPY", "LZ4")]
+    VECTORS = json.load(f)["vectors"]
+INPUTS = dict(codec_inputs.inputs())
+CODEC_NUM = {"SNAPPY": 1, "LZ4_RAW": 7, "ZSTD": 6, "UNCOMPRESSED": 0}
+PAGE_CODEC = {"SNAPPY": "SNAPPY", "LZ4": "LZ4_RAW", "ZSTD": "ZSTD"}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
+PAGES = [fx for fx in pf.load_fixtures() if fx["codec"] in PAGE_CODEC]
+CODECS = ["SNAPPY", "LZ4_RAW", "ZSTD"]
+
+
+def original(v):
+    """The input a vector was made from (ZSTD vectors are named input_l<level>)."""
+    name = v["name"]
+    return INPUTS[name.rsplit("_l", 1)[0] if v["codec"] == "ZSTD" else name]
+
+
+class _Originals:
+    def __getitem__(self, name):
+        return INPUTS[name] if name in INPUTS else INPUTS[name.rsplit("_l", 1)[0]]
+
+
+ORIGINALS = _Originals()
 
 
 def compressed_parts(fx):
@@ -141,19 +158,68 @@ def test_oracle_decompresses_library_streams(orc, v):
 @pytest.mark.parametrize("fx", PAGES, ids=lambda fx: fx["file"] + "." + fx["column"])
 def test_oracle_decompresses_pyarrow_pages(orc, fx):
     import pyarrow as pa
-    codec = "SNAPPY" if fx["codec"] == "SNAPPY" else "LZ4_RAW"
+    codec = PAGE_CODEC[fx["codec"]]
     for body, size in compressed_parts(fx):
         st, out, used = orc.decompress(codec, body, size)
         assert st == 0 and used == len(body)
         assert bytes(out) == (pa.Codec(codec.lower()).decompress(body, size, asbytes=True) if body else b"")
 
 
+def zstd_block(kind, payload, size=None, last=False):
+    """A raw (0) or RLE (1) block: 3-byte header, payload."""
+    n = len(payload) if size is None else size
+    return ((n << 3) | (kind << 1) | int(last)).to_bytes(3, "little") + payload
+
+
+def handmade_zstd():
+    """(stream, original): what the library's streams above do not hold: raw and RLE blocks, a frame without
+    content size, several frames, a skippable frame, a content checksum."""
+    import xxhash
+    rng = np.random.default_rng(8)
+    a, b = bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    magic = (0xFD2FB528).to_bytes(4, "little")
+    # frame 1: window descriptor, no content size; raw, RLE, empty raw, raw
+    f1 = magic + bytes([0x00, 0x58]) + zstd_block(0, a) + zstd_block(1, b"\x07", 70000) + zstd_block(0, b"") + zstd_block(0, b, last=True)
+    o1 = a + b"\x07" * 70000 + b
+    skip = (0x184D2A53).to_bytes(4, "little") + (11).to_bytes(4, "little") + b"hello world"
+    # frame 2: single segment, one-byte content size, content checksum
+    o2 = b"checksummed " * 9
+    f2 = magic + bytes([0x24, len(o2)]) + zstd_block(0, o2, last=True) + (xxhash.xxh64(o2).intdigest() & 0xFFFFFFFF).to_bytes(4, "little")
+    # frame 3: a library frame (compressed blocks), its header rewritten to carry a checksum
+    import pyarrow as pa
+    o3 = (b"the quick brown fox jumps over the lazy dog. " * 400) + a + bytes(range(256)) * 40
+    lib = pa.Codec("zstd", compression_level=3).compress(o3, asbytes=True)
+    assert lib[:4] == magic and not lib[4] & 0x04
+    f3 = lib[:4] + bytes([lib[4] | 0x04]) + lib[5:] + (xxhash.xxh64(o3).intdigest() & 0xFFFFFFFF).to_bytes(4, "little")
+    return f1 + skip + f2 + f3, o1 + o2 + o3
+
+
+def live_zstd_streams():
+    """[(stream, original)] compressed now with the C library: inputs of several blocks at levels that choose
+    other table modes (repeated tables, literals without a tree) than the committed vectors' levels do."""
+    import pyarrow as pa
+    rng = np.random.default_rng(9)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(3000)]
+    text = b" ".join(words[int(i)] for i in rng.zipf(1.3, 150000) % 3000)
+    ints = np.cumsum(rng.integers(0, 50, 120000)).astype("<i8").tobytes()
+    skew = bytes((rng.geometric(0.3, 400000) % 256).astype(np.uint8))
+    out = []
+    for raw in (text, ints, skew, text[:70000] + skew[:90000] + ints[:200000]):
+        for level in (1, 3, 19):
+            out.append((pa.Codec("zstd", compression_level=level).compress(raw, asbytes=True), raw))
+    return out
+
+
 def test_oracle_handmade_streams(orc):
-    for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("LZ4_RAW", handmade_lz4())):
+    import pyarrow as pa
+    for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("LZ4_RAW", handmade_lz4()), ("ZSTD", handmade_zstd())):
         st, out, used = orc.decompress(codec, stream, len(raw))
         assert st == 0 and bytes(out) == raw and used == len(stream)
-        import pyarrow as pa
-        assert pa.Codec(codec.lower()).decompress(stream, len(raw), asbytes=True) == raw  # the C library reads them alike
+        if codec != "ZSTD":  # (the library's one-shot call stops after the first frame)
+            assert pa.Codec(codec.lower()).decompress(stream, len(raw), asbytes=True) == raw  # the C library reads them alike
+    for stream, raw in live_zstd_streams():
+        st, out, used = orc.decompress("ZSTD", stream, len(raw))
+        assert st == 0 and bytes(out) == raw and used == len(stream)
     # broken streams
     D = orc.DECODE
     assert orc.decompress("SNAPPY", b"", 0)[0] == D                       # no preamble
@@ -174,6 +240,18 @@ def test_oracle_handmade_streams(orc):
     assert orc.decompress("LZ4_RAW", b"\x10a\x01", 5)[0] == D              # half an offset
     assert orc.decompress("LZ4_RAW", b"\x1fa\x01\x00\xff", 300)[0] == D    # length bytes run out
     assert orc.decompress("LZ4_RAW", b"\x10a\x01\x00", 5)[:2][1].tobytes() == b"aaaaa"
+    magic = (0xFD2FB528).to_bytes(4, "little")
+    assert orc.decompress("ZSTD", b"", 0)[0] == 0                          # no frame at all: an empty page
+    assert orc.decompress("ZSTD", magic + b"\x20\x00" + zstd_block(0, b"", last=True), 0)[0] == 0
+    assert orc.decompress("ZSTD", magic + b"\x20\x03" + zstd_block(0, b"abc", last=True), 3)[1].tobytes() == b"abc"
+    assert orc.decompress("ZSTD", magic + b"\x20\x04" + zstd_block(0, b"abc", last=True), 3)[0] == D  # content size disagrees
+    assert orc.decompress("ZSTD", magic + b"\x20\x03" + zstd_block(0, b"abc", last=True), 4)[0] == D  # page header disagrees
+    assert orc.decompress("ZSTD", magic + b"\x20\x03" + zstd_block(0, b"abc"), 3)[0] == D             # no last block
+    assert orc.decompress("ZSTD", magic + b"\x21\x01\x03" + zstd_block(0, b"abc", last=True), 3)[0] == D  # wants a dictionary
+    assert orc.decompress("ZSTD", magic + b"\x28\x03" + zstd_block(0, b"abc", last=True), 3)[0] == D  # reserved bit
+    assert orc.decompress("ZSTD", magic + b"\x20\x03" + zstd_block(3, b"abc", last=True), 3)[0] == D  # reserved block type
+    assert orc.decompress("ZSTD", magic + b"\x24\x03" + zstd_block(0, b"abc", last=True) + b"\0\0\0\0", 3)[0] == D  # wrong checksum
+    assert orc.decompress("ZSTD", b"\x28\xb5\x2f\xfc\x20\x00\x01\x00\x00", 0)[0] == D            # wrong magic
 
 
 # ------------------------------------------------------------------------------- GPU
@@ -222,7 +300,7 @@ def check_batch(orc, codec_name, items, results):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+@pytest.mark.parametrize("codec_name", CODECS)
 def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
     import torch
     import parquet_java_amd as pq
@@ -233,11 +311,18 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
         if v["codec"] == codec_name:
             items.append((base64.b64decode(v["compressed"]), v["size"]))
             want.append(ORIGINALS[v["name"]])
-    stream, raw = handmade_snappy() if codec_name == "SNAPPY" else handmade_lz4()
+    stream, raw = {"SNAPPY": handmade_snappy, "LZ4_RAW": handmade_lz4, "ZSTD": handmade_zstd}[codec_name]()
     items.append((stream, len(raw)))
     want.append(raw)
+    if codec_name == "ZSTD":
+        magic = (0xFD2FB528).to_bytes(4, "little")
+        for stream, raw in live_zstd_streams() + [
+                (b"", b""), (magic + b"\x20\x00" + zstd_block(0, b"", last=True), b""),
+                (magic + b"\x20\x03" + zstd_block(0, b"abc", last=True), b"abc")]:
+            items.append((stream, len(raw)))
+            want.append(raw)
     for fx in PAGES:
-        if ("SNAPPY" if fx["codec"] == "SNAPPY" else "LZ4_RAW") == codec_name:
+        if PAGE_CODEC[fx["codec"]] == codec_name:
             for body, size in compressed_parts(fx):
                 items.append((body, size))
                 want.append(None)
@@ -252,7 +337,7 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+@pytest.mark.parametrize("codec_name", CODECS)
 def test_gpu_damaged_streams(orc, codec_name):
     import torch
     import parquet_java_amd as pq
@@ -260,7 +345,15 @@ def test_gpu_damaged_streams(orc, codec_name):
     pq.init(0)
     rng = np.random.default_rng(123)
     base = [(base64.b64decode(v["compressed"]), v["size"]) for v in VECTORS
-            if v["codec"] == codec_name and v["name"] in ("short", "text", "ints", "mixed", "run_3", "timestamps")]
+            if v["codec"] == codec_name and v["name"].rsplit("_l", 1)[0] in ("short", "text", "ints", "mixed", "run_3", "timestamps")]
+    if codec_name == "ZSTD":
+        magic = (0xFD2FB528).to_bytes(4, "little")
+        base += [(s, len(r)) for s, r in live_zstd_streams()[:6]] + [(handmade_zstd()[0], len(handmade_zstd()[1]))]
+        heads = [magic + b"\x20\x04" + zstd_block(0, b"abc", last=True), magic + b"\x20\x03" + zstd_block(0, b"abc"),
+                 magic + b"\x21\x01\x03" + zstd_block(0, b"abc", last=True), magic + b"\x28\x03" + zstd_block(0, b"abc", last=True),
+                 magic + b"\x20\x03" + zstd_block(3, b"abc", last=True),
+                 magic + b"\x24\x03" + zstd_block(0, b"abc", last=True) + b"\0\0\0\0", b"\x28\xb5\x2f\xfc\x20\x00\x01\x00\x00"]
+        check_batch(orc, codec_name, [(h, 3) for h in heads], run_batch(pq, gh, torch, CODEC_NUM[codec_name], [(h, 3) for h in heads]))
     items = []
     for trial in range(150):
         stream, size = base[trial % len(base)]
@@ -285,12 +378,13 @@ def test_gpu_stored_parts_and_host_entry(orc):
         assert st == 0 and data == stream and used == size
     (st, data, used), = run_batch(pq, gh, torch, 0, [(b"abcdef", 4)])
     assert st == orc.DECODE and data == b"abcd"
-    assert pq.lib.pqd_codec_supported(1) and pq.lib.pqd_codec_supported(7) and not pq.lib.pqd_codec_supported(2)
+    assert pq.lib.pqd_codec_supported(1) and pq.lib.pqd_codec_supported(7) and pq.lib.pqd_codec_supported(6)
+    assert not pq.lib.pqd_codec_supported(2)
     # the host entry behind the BytesDecompressor mirror
-    for name in ("SNAPPY", "LZ4_RAW"):
+    for name in CODECS:
         d = pq.BytesDecompressor(name)
         for v in VECTORS:
-            if v["codec"] == name and v["name"] in ("empty", "short", "text", "random"):
+            if v["codec"] == name and v["name"].rsplit("_l", 1)[0] in ("empty", "short", "text", "random"):
                 assert d.decompress(base64.b64decode(v["compressed"]), v["size"]) == ORIGINALS[v["name"]]
         with pytest.raises(IOError):
             d.decompress(b"\x05\x10abcd", 5)
