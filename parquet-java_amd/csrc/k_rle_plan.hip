@@ -781,6 +781,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.reserved[0] = V;  // marks the chunk as regular: run r0 + i = values start0 + i*V, bytes src0 + i*S
               hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
+              // (k_dict_pages_regular8 takes batches of such chunks over four-quarter dictionaries only)
+              if (elem == 8 && c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + 3, 1u);
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
               uint32_t packed = 0;
@@ -924,6 +926,34 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         hd->reserved[1] = 0;
       }
       __syncthreads();
+      // Chunks of 8-byte dictionary pages that are nothing but whole bit-packed runs at one distance from
+      // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
+      // chunks; the others are counted, and a batch without any is gathered by k_dict_pages_regular8.
+      if (want_dict && elem == 8) {
+        const uint32_t s0 = chunk[0].start4, c0 = chunk[0].src;
+        const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
+        bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
+                  d.dict_len > 3u * DP_QUARTER_ENTRIES;  // (that kernel sweeps four quarters per plane)
+        uint32_t V = 1u << 20, S = 0;  // a single run: every unit lies in run 0
+        if (k >= 2) {
+          V = (chunk[1].start4 >> 2) - (s0 >> 2);
+          S = chunk[1].src - c0;
+          ok = ok && V != 0 && (V & 3u) == 0 && V <= (1u << 20);
+        }
+        bool bad = false;
+        for (uint32_t i = tid; i < k; i += PLAN_THREADS)
+          bad = bad || chunk[i].start4 != s0 + ((i * V) << 2) || chunk[i].src != c0 + i * S;
+        ok = ok && __builtin_amdgcn_ballot_w64(bad) == 0;
+        if (tid == 0) {
+          RleChunkHead* hd = reinterpret_cast<RleChunkHead*>(chunk + SEG_HEAD_SLOT);
+          if (ok) {
+            hd->reserved[0] = V;
+            hd->reserved[1] = S;
+          } else {
+            atomicAdd(cursor + 3, 1u);
+          }
+        }
+      }
       uint8_t* table = reinterpret_cast<uint8_t*>(chunk + SEG_TABLE_SLOT);
       for (uint32_t b = tid; b < (uint32_t)SEG_TABLE_BLOCKS; b += PLAN_THREADS) {
         const uint32_t first = v0 + b * SEG_BLOCK;

@@ -103,10 +103,52 @@ __device__ __forceinline__ void plane_pass(const uint8_t* planes, uint32_t lds0,
     constexpr int NX = DESC ? S - 1 : S + 1;
     load_64k(planes + (size_t)NX * BUF, lds0 + (uint32_t)(NX & 1) * BUF, wave, lane);
   }
-  if (SKEL == 1) return;
+  if (SKEL == 1 || SKEL == 3) return;
 #pragma unroll
   for (int r = 0; r < R; ++r) lookup<PL, QT>(vlo[r], vhi[r], addr[r], mhi[r], mlo[r]);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Early refill: the quarter of pass Q + 2 is requested right behind the lookups of pass Q (after a barrier for the
+// LDS reads alone), before the wait for pass Q + 1's quarter: two transfers in flight instead of one.
+template <int R, int Q, bool DESC, int SKEL>
+__device__ __forceinline__ void plane_pass_early(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                                 uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
+                                                 const uint64_t (&mhi)[R], const uint64_t (&mlo)[R]) {
+  constexpr int S = DESC ? 7 - Q : Q;
+  constexpr int PL = S >> 2, QT = S & 3;
+  if (Q >= 2) {  // this pass's quarter has landed (the one behind it may still be on its way)
+    if (Q < 7)
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (SKEL != 1 && SKEL != 3) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) lookup<PL, QT>(vlo[r], vhi[r], addr[r], mhi[r], mlo[r]);
+  }
+  if (Q + 2 < 8) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everybody is done reading this buffer
+    if (SKEL != 2) {
+      constexpr int NX = DESC ? S - 2 : S + 2;
+      load_64k(planes + (size_t)NX * BUF, lds0 + (uint32_t)(NX & 1) * BUF, wave, lane);
+    }
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+template <int R, bool DESC, int SKEL>
+__device__ __forceinline__ void plane_sweep_early(const uint8_t* planes, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                            uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
+                                            const uint64_t (&mhi)[R], const uint64_t (&mlo)[R]) {
+  plane_pass_early<R, 0, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 1, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 2, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 3, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 4, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 5, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 6, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+  plane_pass_early<R, 7, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
 }
 
 template <int R, bool DESC, int SKEL>
@@ -123,7 +165,7 @@ __device__ __forceinline__ void plane_sweep(const uint8_t* planes, uint32_t lds0
   plane_pass<R, 7, DESC, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
 }
 
-template <int R, int SKEL>
+template <int R, int SKEL, int SCHED = 0>
 __global__ __launch_bounds__(THREADS) void k_planes(const uint16_t* __restrict__ ids, const uint8_t* __restrict__ planes,
                                                     uint64_t* __restrict__ out, size_t n) {
   extern __shared__ u32x4 lds4[];
@@ -162,15 +204,134 @@ __global__ __launch_bounds__(THREADS) void k_planes(const uint16_t* __restrict__
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
       const size_t u = nb0 / 4 + (size_t)k * THREADS + tid;
-      nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+      nxt[k] = (SKEL != 3 && u * 4 < n) ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
     }
     uint32_t vlo[R], vhi[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
-    if (!descending)
-      plane_sweep<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
-    else
-      plane_sweep<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+    if (SCHED == 0) {
+      if (!descending)
+        plane_sweep<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+      else
+        plane_sweep<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+    } else {
+      if (!descending)
+        plane_sweep_early<R, false, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+      else
+        plane_sweep_early<R, true, SKEL>(planes, lds0, wave, lane, vlo, vhi, addr, mhi, mlo);
+    }
+    descending = !descending;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = b0 / 4 + (size_t)k * THREADS + tid;
+      if (SKEL != 3 && u * 4 < n) {
+        store_nt(out + u * 4, vlo[4 * k], vhi[4 * k], vlo[4 * k + 1], vhi[4 * k + 1]);
+        store_nt(out + u * 4 + 2, vlo[4 * k + 2], vhi[4 * k + 2], vlo[4 * k + 3], vhi[4 * k + 3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// D. the product's form of the lookup: the quarter of every id kept as a byte (four values per register), a
+// byte-selecting compare puts the quarter's lanes into EXEC (one VALU instruction per lookup, no scalar masks).
+template <int J>
+__device__ __forceinline__ void tag_lookup(uint32_t& dst, uint32_t addr, uint32_t tags, uint32_t quarter, uint64_t all) {
+#define PQD_TAG_LOOKUP(SEL)                                                                              \
+  asm volatile("v_cmpx_eq_u32_sdwa vcc, %2, %3 src0_sel:" SEL " src1_sel:DWORD\n\tds_read_b32 %0, %1\n\ts_mov_b64 exec, %4" \
+               : "+v"(dst)                                                                                 \
+               : "v"(addr), "v"(tags), "s"(quarter), "s"(all)                                              \
+               : "vcc")
+  if (J == 0) PQD_TAG_LOOKUP("BYTE_0");
+  if (J == 1) PQD_TAG_LOOKUP("BYTE_1");
+  if (J == 2) PQD_TAG_LOOKUP("BYTE_2");
+  if (J == 3) PQD_TAG_LOOKUP("BYTE_3");
+#undef PQD_TAG_LOOKUP
+}
+
+template <int R, int SHARE>
+__global__ __launch_bounds__(THREADS) void k_planes_tags(const uint16_t* __restrict__ ids, const uint8_t* __restrict__ planes,
+                                                         uint64_t* __restrict__ out, size_t n) {
+  extern __shared__ u32x4 lds4[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSP uint8_t*)lds4;
+  constexpr int UNITS = R / 4;
+  const uint32_t tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63u;
+  const size_t batch = (size_t)THREADS * R;
+  const size_t n_batches = (n + batch - 1) / batch;
+  size_t bi, bi_end, bi_step;
+  if (SHARE) {  // contiguous shares, as the product
+    const size_t share = (n_batches + gridDim.x - 1) / gridDim.x;
+    bi = blockIdx.x * share;
+    bi_end = bi + share < n_batches ? bi + share : n_batches;
+    bi_step = 1;
+  } else {
+    bi = blockIdx.x;
+    bi_end = n_batches;
+    bi_step = gridDim.x;
+  }
+  if (bi >= bi_end) return;
+  bool descending = false;
+  load_64k(planes, lds0, wave, lane);
+  load_64k(planes + BUF, lds0 + BUF, wave, lane);
+  u32x2 nxt[UNITS];
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) {
+    const size_t u = bi * batch / 4 + (size_t)k * THREADS + tid;
+    nxt[k] = u * 4 < n ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+  }
+  wg_barrier();
+  const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+  for (; bi < bi_end; bi += bi_step) {
+    const size_t b0 = bi * batch;
+    uint32_t addr[R], tags[UNITS];
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const uint32_t i0 = nxt[k].x & 0xFFFF, i1 = nxt[k].x >> 16, i2 = nxt[k].y & 0xFFFF, i3 = nxt[k].y >> 16;
+      tags[k] = (i0 >> 14) | ((i1 >> 14) << 8) | ((i2 >> 14) << 16) | ((i3 >> 14) << 24);
+      addr[4 * k] = (i0 << 2) & 0x1FFFFu;
+      addr[4 * k + 1] = (i1 << 2) & 0x1FFFFu;
+      addr[4 * k + 2] = (i2 << 2) & 0x1FFFFu;
+      addr[4 * k + 3] = (i3 << 2) & 0x1FFFFu;
+    }
+    const size_t nb = bi + bi_step;
+#pragma unroll
+    for (int k = 0; k < UNITS; ++k) {
+      const size_t u = nb * batch / 4 + (size_t)k * THREADS + tid;
+      nxt[k] = (nb < bi_end && u * 4 < n) ? *reinterpret_cast<const u32x2*>(ids + u * 4) : u32x2{0, 0};
+    }
+    uint32_t vlo[R], vhi[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) vlo[r] = vhi[r] = 0;
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint32_t s = descending ? 7 - q : q;
+      if (q == 0)
+        wg_barrier_keep<R / 4>();
+      else
+        wg_barrier();
+      if (q >= 1 && q + 1 < 8) {
+        const uint32_t nx = descending ? s - 1 : s + 1;
+        load_64k(planes + (size_t)nx * BUF, lds0 + (nx & 1u) * BUF, wave, lane);
+      }
+      const uint32_t qt = uni(s & 3u);
+      if (s < 4) {
+#pragma unroll
+        for (int k = 0; k < UNITS; ++k) {
+          tag_lookup<0>(vlo[4 * k], addr[4 * k], tags[k], qt, all);
+          tag_lookup<1>(vlo[4 * k + 1], addr[4 * k + 1], tags[k], qt, all);
+          tag_lookup<2>(vlo[4 * k + 2], addr[4 * k + 2], tags[k], qt, all);
+          tag_lookup<3>(vlo[4 * k + 3], addr[4 * k + 3], tags[k], qt, all);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < UNITS; ++k) {
+          tag_lookup<0>(vhi[4 * k], addr[4 * k], tags[k], qt, all);
+          tag_lookup<1>(vhi[4 * k + 1], addr[4 * k + 1], tags[k], qt, all);
+          tag_lookup<2>(vhi[4 * k + 2], addr[4 * k + 2], tags[k], qt, all);
+          tag_lookup<3>(vhi[4 * k + 3], addr[4 * k + 3], tags[k], qt, all);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     descending = !descending;
 #pragma unroll
     for (int k = 0; k < UNITS; ++k) {
@@ -251,20 +412,38 @@ int main() {
     fflush(stdout);
   };
   float us;
-#define RUN_PLANES(R, SKEL)                                                                                                    \
+#define RUN_PLANES(R, SKEL) RUN_PLANES_S(R, SKEL, 0)
+#define RUN_PLANES_S(R, SKEL, SCHED)                                                                                                \
   {                                                                                                                            \
-    CHECK(hipFuncSetAttribute((const void*)k_planes<R, SKEL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));           \
-    us = time_it([&] { hipLaunchKernelGGL((k_planes<R, SKEL>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, planes, out, n); }); \
+    CHECK(hipFuncSetAttribute((const void*)k_planes<R, SKEL, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));           \
+    us = time_it([&] { hipLaunchKernelGGL((k_planes<R, SKEL, SCHED>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, planes, out, n); }); \
     if (!SKEL) check("planes"); else CHECK(hipMemset(out, 0, n * 8));                                                                                                \
     char nm[96];                                                                                                               \
-    snprintf(nm, sizeof nm, "dword planes in quarters  R=%d%s", R, SKEL == 1 ? "  (no lookups: DMA + ids + stores)" : SKEL == 2 ? "  (no DMA: ids + lookups + stores)" : "");                           \
+    snprintf(nm, sizeof nm, "dword planes in quarters  R=%d%s%s", R, SCHED ? " early" : "", SKEL == 3 ? "  (DMA only)" : SKEL == 1 ? "  (no lookups: DMA + ids + stores)" : SKEL == 2 ? "  (no DMA: ids + lookups + stores)" : "");                           \
     report(nm, us);                                                                                                            \
   }
+#define RUN_TAGS(R, SHARE)                                                                                                     \
+  {                                                                                                                            \
+    CHECK(hipFuncSetAttribute((const void*)k_planes_tags<R, SHARE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));     \
+    us = time_it([&] { hipLaunchKernelGGL((k_planes_tags<R, SHARE>), dim3(256), dim3(THREADS), 2 * BUF, 0, ids, planes, out, n); }); \
+    check("tags");                                                                                                             \
+    report(SHARE ? "byte tags + cmpx, contiguous shares" : "byte tags + cmpx, grid stride", us);                               \
+  }
   RUN_PLANES(20, 0);
+  RUN_TAGS(20, 0);
+  RUN_TAGS(20, 1);
+  RUN_PLANES(20, 0);
+  RUN_TAGS(20, 0);
+  RUN_TAGS(20, 1);
+  return 0;
   RUN_PLANES(20, 1);
   RUN_PLANES(20, 2);
-  RUN_PLANES(16, 0);
-  RUN_PLANES(24, 0);
+  RUN_PLANES(20, 3);
+  RUN_PLANES_S(20, 0, 1);
+  RUN_PLANES_S(20, 1, 1);
+  RUN_PLANES_S(20, 2, 1);
+  RUN_PLANES_S(20, 3, 1);
   RUN_PLANES(20, 0);
+  RUN_PLANES_S(20, 0, 1);
   return 0;
 }
