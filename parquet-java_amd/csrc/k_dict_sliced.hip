@@ -479,18 +479,344 @@ __device__ __forceinline__ void sweep_8_byte_dictionary(uint32_t (&id)[R], uint3
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The gather for batches in which EVERY chunk is regular: nothing but whole bit-packed runs, one
+// behind the other at a fixed distance (ids of a high-cardinality column as parquet-java writes them:
+// 504-value runs behind one-byte headers; the plan kernel marks such chunks in their header and counts
+// the others in counter 3 of the call's counter block).  The run of a unit then follows from its index,
+// so the front end of the general kernel (chunk records in LDS, block table, segment search,
+// classification, the list of straddling units, the chunk-end barrier) is not needed: a chunk is its
+// 64-byte header and first segment, read by 18 lanes of every wave two chunks ahead.  The dictionaries
+// are those of more than three quarters per plane (the plan kernel counts chunks of smaller ones with the
+// irregular ones), which makes the sweep eight passes known at compile time: the quarter of an id is kept
+// as two lane masks in scalar registers and a lookup costs no vector instruction; and because no chunk
+// record travels by LDS-DMA, passes 0 and 1 (quarters already resident) need no wait for memory
+// operations, so the stores of the chunk before drain behind them instead of in front of them.
+
+struct RegHead {
+  const PQD_GLOBAL uint32_t* words;  // the page's stream rounded down to a dword
+  uint32_t in_off, max_wi;           // data & 3; largest dword index a 12-byte unit load may start at
+  uint32_t v0, v1, w;
+  uint32_t run_values, run_stride, start0, src0;
+  float rcp_values;
+};
+
+// Dword `lane` of the chunk's header (lanes 0..15) and its first segment (lanes 16, 17).
+__device__ __forceinline__ uint32_t load_chunk_head(const RleSeg* pool, uint32_t chunk, bool valid, uint32_t lane) {
+  const PQD_GLOBAL uint32_t* base = (const PQD_GLOBAL uint32_t*)(pool + (size_t)chunk * SEG_CHUNK);
+  const uint32_t idx = lane < 16u ? (uint32_t)SEG_HEAD_SLOT * 2u + lane : (lane < 18u ? lane - 16u : 0u);
+  return valid ? base[idx] : 0u;  // all zero: an empty chunk
+}
+#define PQD_HEAD_DWORD(hv, i) ((uint32_t)__builtin_amdgcn_readlane((int)(hv), (i)))
+
+__device__ __forceinline__ RegHead read_reg_head(uint32_t hv) {
+  RegHead h;
+  const uint32_t dlo = PQD_HEAD_DWORD(hv, 0), dhi = PQD_HEAD_DWORD(hv, 1);
+  h.in_off = dlo & 3u;
+  h.words = (const PQD_GLOBAL uint32_t*)((((uint64_t)dhi << 32) | dlo) - h.in_off);
+  const uint32_t data_len = PQD_HEAD_DWORD(hv, 8);
+  const uint32_t last_word = data_len ? (h.in_off + data_len - 1u) >> 2 : 0u;
+  h.max_wi = last_word >= 2u ? last_word - 2u : 0u;  // (a regular chunk's page holds at least three dwords)
+  h.v0 = PQD_HEAD_DWORD(hv, 4);
+  h.v1 = PQD_HEAD_DWORD(hv, 5);
+  h.w = PQD_HEAD_DWORD(hv, 7);
+  h.run_values = PQD_HEAD_DWORD(hv, 14);
+  h.run_stride = PQD_HEAD_DWORD(hv, 15);
+  h.start0 = PQD_HEAD_DWORD(hv, 16) >> 2;
+  h.src0 = PQD_HEAD_DWORD(hv, 17);
+  h.rcp_values = 1.0f / (float)(h.run_values ? h.run_values : 1u);
+  return h;
+}
+
+// Issues the 12-byte loads of a regular chunk's units.  meta: bits 0..4 the bit offset inside the first
+// dword loaded, bits 8..9 by how many dwords the load was moved down to stay inside the page.
+// (`valid` false: nothing to fetch; the loads are issued all the same, from `spare`, so that their number is fixed.)
+template <int UNITS>
+__device__ __forceinline__ void fetch_regular(const RegHead& h, bool valid, const void* spare, uint32_t tid, u32x3_a4 (&raw)[UNITS],
+                                              uint32_t (&meta)[UNITS]) {
+  uint32_t wi[UNITS];
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) {
+    const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+    const uint32_t rel = (g0 < h.v1 ? g0 : h.v0) - h.start0;  // far below 2^24: exact as a float
+    uint32_t q = (uint32_t)((float)rel * h.rcp_values);
+    q -= q * h.run_values > rel ? 1u : 0u;
+    q += (q + 1u) * h.run_values <= rel ? 1u : 0u;
+    const uint32_t byte0 = h.in_off + h.src0 + q * h.run_stride;
+    const uint32_t bitrel = (byte0 & 3u) * 8 + (rel - q * h.run_values) * h.w;
+    const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
+    const uint32_t delta = w_i > h.max_wi ? w_i - h.max_wi : 0u;  // the page's last dwords: load what is there
+    wi[k] = valid ? w_i - delta : 0u;
+    meta[k] = (bitrel & 31u) | (delta << 8);
+  }
+  const PQD_GLOBAL uint32_t* words = valid ? h.words : (const PQD_GLOBAL uint32_t*)spare;
+#pragma unroll
+  for (int k = 0; k < UNITS; ++k) raw[k] = *(const PQD_GLOBAL u32x3_a4*)(words + wi[k]);
+}
+
+// One lookup in the quarter QT of a dictionary plane: the quarter of every id is kept as two lane masks
+// (bit 15 and bit 14 of the id, computed once per chunk), one scalar instruction puts the quarter's lanes
+// into EXEC, one 4-byte LDS read fills their result register: no vector arithmetic per lookup.  (All 64
+// lanes of every wave are active around the call.)
+template <int QT>
+__device__ __forceinline__ void mask_lookup(uint32_t& dst, uint32_t addr, uint64_t hi, uint64_t lo) {
+#define PQD_MASK_LOOKUP(SETEXEC) \
+  asm volatile(SETEXEC "\n\tds_read_b32 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(addr), "s"(hi), "s"(lo) : "scc")
+  if (QT == 0) PQD_MASK_LOOKUP("s_nor_b64 exec, %2, %3");
+  if (QT == 1) PQD_MASK_LOOKUP("s_andn2_b64 exec, %3, %2");
+  if (QT == 2) PQD_MASK_LOOKUP("s_andn2_b64 exec, %2, %3");
+  if (QT == 3) PQD_MASK_LOOKUP("s_and_b64 exec, %2, %3");
+#undef PQD_MASK_LOOKUP
+}
+
+// Quarter `ps & 3` of plane `ps >> 2` of a four-quarter dictionary into LDS buffer (quarter & 1).
+__device__ __forceinline__ void load_plane_quarter(const uint8_t* slot_base, uint32_t entries, uint32_t ps, uint32_t lds0,
+                                                   uint32_t wave, uint32_t lane) {
+  const uint32_t qt = ps & 3u;
+  const uint32_t n_here = entries - qt * DP_QUARTER_ENTRIES < DP_QUARTER_ENTRIES ? entries - qt * DP_QUARTER_ENTRIES : DP_QUARTER_ENTRIES;
+  load_slice(slot_base + (size_t)(ps >> 2) * DP_PLANE_BYTES + (size_t)qt * DS_SLICE_BYTES, n_here * 4u,
+             lds0 + (qt & 1u) * DS_SLICE_BYTES, wave, lane);
+}
+
+// Pass Q (0..NP-1 in sweep order, NP = 4 for a 4-byte dictionary, which is its own single plane, 8 for the
+// two planes of an 8-byte one; DESC: from the last quarter of the last plane down) of the sweep of a
+// four-quarter dictionary.  Passes 0 and 1 find their quarters resident (the sweep before ended with
+// them, in the other direction).  Barriers: none in front of pass 0; for LDS reads in front of pass 1
+// (the quarter of pass 2 is about to overwrite the buffer pass 0 read); a full one from pass 2 on (the
+// quarter requested one pass ago has landed, and everybody is done with the other buffer).
+//   The next chunk's packed dwords are requested in pass NP - 2, right behind that pass's quarter
+// request (`prefetch` issues exactly KEEP loads), and the barrier of the pass after it leaves those KEEP
+// loads in flight (the counters are in issue order): requested in front of the sweep they would be
+// waited for at pass 2's barrier, a microsecond later, which is less than a load from HBM takes while
+// the chip is writing.
+template <int R, int NP, int Q, bool DESC, int KEEP, typename Prefetch>
+__device__ __forceinline__ void regular_pass(const uint8_t* slot_base, uint32_t entries, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                             uint32_t (&vlo)[R], uint32_t (&vhi)[NP == 8 ? R : 1], const uint32_t (&addr)[R],
+                                             const uint64_t (&mhi)[R], const uint64_t (&mlo)[R], Prefetch prefetch) {
+  constexpr int S = DESC ? NP - 1 - Q : Q;  // plane S >> 2, quarter S & 3
+  constexpr int PL = S >> 2, QT = S & 3;
+  if (Q == 1) wg_barrier_lds();
+  if (Q >= 2 && Q != NP - 1) wg_barrier();
+  if (Q >= 2 && Q == NP - 1) wg_barrier_keep<KEEP>();
+  if (Q >= 1 && Q + 1 < NP) load_plane_quarter(slot_base, entries, (uint32_t)(DESC ? S - 1 : S + 1), lds0, wave, lane);
+  if (Q == NP - 2) prefetch();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (PL == 0)
+      mask_lookup<QT>(vlo[r], addr[r], mhi[r], mlo[r]);
+    else
+      mask_lookup<QT>(vhi[NP == 8 ? r : 0], addr[r], mhi[r], mlo[r]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are invisible to the compiler
+}
+
+template <int R, int NP, bool DESC, int KEEP, typename Prefetch>
+__device__ __forceinline__ void regular_sweep(const uint8_t* slot_base, uint32_t entries, uint32_t lds0, uint32_t wave, uint32_t lane,
+                                              uint32_t (&vlo)[R], uint32_t (&vhi)[NP == 8 ? R : 1], const uint32_t (&addr)[R],
+                                              const uint64_t (&mhi)[R], const uint64_t (&mlo)[R], Prefetch prefetch) {
+  regular_pass<R, NP, 0, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+  regular_pass<R, NP, 1, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+  regular_pass<R, NP, 2, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+  regular_pass<R, NP, 3, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+  if constexpr (NP == 8) {
+    regular_pass<R, NP, 4, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+    regular_pass<R, NP, 5, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+    regular_pass<R, NP, 6, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+    regular_pass<R, NP, 7, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
+  }
+}
+
+// The whole batch, for one workgroup of k_dict_pages_sliced (which calls it when counter 3 of the call's
+// counter block is zero: no chunk of the batch is irregular).  `lds0`: LDS byte address of the dynamic block.
+template <int ELEM>
+__device__ __forceinline__ void gather_regular_batch(pqd_page_result* __restrict__ results, const RleSeg* __restrict__ pool,
+                                                     uint32_t pool_chunks, const uint32_t* __restrict__ cursor, uint32_t n_pages,
+                                                     const uint8_t* __restrict__ plane_area, uint32_t lds0, uint32_t stagger) {
+  constexpr int R = DS_R;
+  constexpr int UNITS = R / 4;
+  constexpr int NP = ELEM == 8 ? 8 : 4;  // passes per sweep
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wave = uni(tid >> 6), lane = tid & 63u;
+
+  uint64_t tag_dict = 0;  // the dictionary whose quarters the LDS buffers hold
+  uint32_t tag_len = 0;
+  bool descending = false;
+
+  // workgroup b takes chunks b, b + grid, b + 2 * grid, ...: at any moment the workgroups of the chip
+  // read and write one window of the batch that moves along (PQD_REGULAR_SHARES: contiguous shares instead)
+  uint32_t n_chunks = n_pages + uni(cursor[0]);
+  if (n_chunks > pool_chunks) n_chunks = pool_chunks;
+  const uint32_t share = (n_chunks + gridDim.x - 1) / gridDim.x;
+#ifdef PQD_REGULAR_SHARES
+  uint32_t chunk = blockIdx.x * share;
+  if (chunk >= n_chunks) return;
+  n_chunks = chunk + share < n_chunks ? chunk + share : n_chunks;  // from here on: the end of this workgroup's share
+  const uint32_t step = 1;
+#else
+  uint32_t chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  const uint32_t step = gridDim.x;
+#endif
+
+  uint32_t hv = load_chunk_head(pool, chunk, true, lane);                             // this chunk
+  uint32_t hv1 = load_chunk_head(pool, chunk + step, chunk + step < n_chunks, lane);  // the next one
+  u32x3_a4 raw[UNITS];
+  uint32_t meta[UNITS];
+  {
+    const RegHead h0 = read_reg_head(hv);
+    // staggered start of long batches over large dictionaries (see the general kernel)
+    if (share >= 16u && PQD_HEAD_DWORD(hv, 11) > DP_QUARTER_ENTRIES) {
+      const uint32_t phase = (blockIdx.x >> 3) & 31u;
+      for (uint32_t i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    fetch_regular<UNITS>(h0, h0.v1 > h0.v0, pool, tid, raw, meta);
+  }
+
+  for (;;) {
+    const RegHead h = read_reg_head(hv);
+    const uint32_t next_chunk = chunk + step;
+    const bool has_next = next_chunk < n_chunks;
+    // the header of the chunk after the next one is requested now; the next chunk's is here already
+    const uint32_t hv2 = load_chunk_head(pool, next_chunk + step, has_next && next_chunk + step < n_chunks, lane);
+    if (h.v1 > h.v0) {  // (uniform over the workgroup; an empty chunk belongs to a page the plan kernel finished or left over)
+      const uint32_t v0 = h.v0, n_out = h.v1;
+      const uint32_t dict_len = PQD_HEAD_DWORD(hv, 11);
+      const uint64_t dict_addr = ((uint64_t)PQD_HEAD_DWORD(hv, 13) << 32) | PQD_HEAD_DWORD(hv, 12);
+      const uint64_t out_addr = ((uint64_t)PQD_HEAD_DWORD(hv, 3) << 32) | PQD_HEAD_DWORD(hv, 2);
+      const uint32_t page = PQD_HEAD_DWORD(hv, 10);
+      const uint32_t slot1 = PQD_HEAD_DWORD(hv, 6) >> 16;
+      const uint32_t entries = dict_len < 65536u ? dict_len : 65536u;  // more than three quarters (the plan kernel saw to it)
+      // the planes of an 8-byte dictionary are its plane copy; a 4-byte dictionary is its own single plane
+      const uint8_t* slot_base = ELEM == 8 ? plane_area + (size_t)(slot1 - 1u) * DP_SLOT_BYTES : reinterpret_cast<const uint8_t*>(dict_addr);
+      if (dict_addr != tag_dict || dict_len != tag_len) {  // first chunk, another dictionary: the two quarters the sweep starts with
+        tag_dict = dict_addr;
+        tag_len = dict_len;
+        wg_barrier();  // nobody still reads the buffers
+        load_plane_quarter(slot_base, entries, descending ? (uint32_t)NP - 1u : 0u, lds0, wave, lane);
+        load_plane_quarter(slot_base, entries, descending ? (uint32_t)NP - 2u : 1u, lds0, wave, lane);
+        wg_barrier();
+      }
+
+      // ---- 1. ids into registers (their packed dwords were requested one chunk ago)
+      uint32_t id[R];
+      const uint32_t w = h.w;
+#pragma unroll
+      for (int k = 0; k < UNITS; ++k) {
+        uint32_t d0 = raw[k].x, d1 = raw[k].y, d2 = raw[k].z;
+        const uint32_t dl = meta[k] >> 8;
+        if (__builtin_amdgcn_ballot_w64(dl != 0)) {  // rare: a unit in the page's last dwords
+          d0 = dl == 1 ? d1 : (dl == 2 ? d2 : d0);
+          d1 = dl == 1 ? d2 : (dl == 2 ? 0u : d1);
+          d2 = dl == 0 ? d2 : 0u;
+        }
+        const uint32_t b = meta[k] & 31u;
+        const uint32_t lo = funnel_shr(d0, d1, b), hi = funnel_shr(d1, d2, b);
+        id[4 * k] = unit_value(lo, hi, w, 0);
+        id[4 * k + 1] = unit_value(lo, hi, w, 1);
+        id[4 * k + 2] = unit_value(lo, hi, w, 2);
+        id[4 * k + 3] = unit_value(lo, hi, w, 3);
+      }
+
+      // ---- 2. ids beyond the dictionary (see the general kernel)
+      const uint32_t id_bits = (w + 7u) & ~7u;
+      if (id_bits >= 32 || (1u << id_bits) > dict_len) {
+        uint32_t bad = ~0u;
+#pragma unroll
+        for (int k = UNITS - 1; k >= 0; --k) {
+          const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            const bool over = id[4 * k + j] >= dict_len;
+            bad = (over && g0 + j < n_out) ? g0 + j : bad;
+            id[4 * k + j] = over ? 0u : id[4 * k + j];
+          }
+        }
+        if (bad != ~0u) {  // the plan kernel wrote the page's result; an id beyond the dictionary comes before whatever ended the header walk
+          atomicMin(&results[page].values_written, bad);
+          results[page].status = PQD_DICT_OOB;
+        }
+      }
+
+      // ---- 3. (the next chunk's packed dwords are requested inside the sweep)
+      const RegHead nh = read_reg_head(hv1);
+      auto prefetch = [&]() { fetch_regular<UNITS>(nh, has_next && nh.v1 > nh.v0, pool, tid, raw, meta); };
+
+      // ---- 4. gather: an id's LDS address is (4 * id) & 0x1FFFF in every pass, its quarter two lane masks
+      uint32_t vlo[R], vhi[ELEM == 8 ? R : 1];
+      uint64_t mhi[R], mlo[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        vlo[r] = 0;
+        vhi[ELEM == 8 ? r : 0] = 0;
+        mhi[r] = __builtin_amdgcn_ballot_w64(id[r] >= 0x8000u);
+        id[r] = (id[r] << 2) & 0x1FFFFu;
+        mlo[r] = __builtin_amdgcn_ballot_w64(id[r] >= 0x10000u);
+      }
+      if (!descending)
+        regular_sweep<R, NP, false, UNITS>(slot_base, entries, lds0, wave, lane, vlo, vhi, id, mhi, mlo, prefetch);
+      else
+        regular_sweep<R, NP, true, UNITS>(slot_base, entries, lds0, wave, lane, vlo, vhi, id, mhi, mlo, prefetch);
+      descending = !descending;
+
+      // ---- 5. store, 16 bytes per lane per instruction
+#pragma unroll
+      for (int k = 0; k < UNITS; ++k) {
+        const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
+        if (g0 >= n_out) continue;
+        if constexpr (ELEM == 4) {
+          PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)out_addr + g0;
+          if (g0 + 4 <= n_out) {
+            u32x4_a4 r4 = {vlo[4 * k], vlo[4 * k + 1], vlo[4 * k + 2], vlo[4 * k + 3]};
+            PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o), r4);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (g0 + j < n_out) o[j] = vlo[4 * k + j];
+          }
+        } else {
+          PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)out_addr + g0;
+          if (g0 + 4 <= n_out) {
+            u32x4_a4 r0 = {vlo[4 * k], vhi[ELEM == 8 ? 4 * k : 0], vlo[4 * k + 1], vhi[ELEM == 8 ? 4 * k + 1 : 0]};
+            u32x4_a4 r1 = {vlo[4 * k + 2], vhi[ELEM == 8 ? 4 * k + 2 : 0], vlo[4 * k + 3], vhi[ELEM == 8 ? 4 * k + 3 : 0]};
+            PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o), r0);
+            PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o + 2), r1);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (g0 + j < n_out) {
+                u32x2_a4 x = {vlo[4 * k + j], vhi[ELEM == 8 ? 4 * k + j : 0]};
+                o[j] = x;
+              }
+          }
+        }
+      }
+    } else if (has_next) {
+      const RegHead nh = read_reg_head(hv1);
+      fetch_regular<UNITS>(nh, nh.v1 > nh.v0, pool, tid, raw, meta);
+    }
+    if (!has_next) break;
+    hv = hv1;
+    hv1 = hv2;
+    chunk = next_chunk;
+  }
+}
+#undef PQD_HEAD_DWORD
+
 template <int ELEM>
 __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_result* __restrict__ results,
                                                                   const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                                   const uint32_t* __restrict__ cursor, uint32_t n_pages,
                                                                   const uint8_t* __restrict__ plane_area,
-                                                                  uint32_t regular_elsewhere PROF_PARAM) {
-  // a batch made of regular chunks only has been gathered by k_dict_pages_regular8 (launched in front of this kernel)
-  if (regular_elsewhere && __builtin_amdgcn_readfirstlane(cursor[3]) == 0u) return;
+                                                                  uint32_t regular_allowed PROF_PARAM) {
   extern __shared__ u32x4 lds4[];
   uint8_t* lds = reinterpret_cast<uint8_t*>(lds4);
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(PQD_LDS uint8_t*)lds;  // LDS byte address of the dynamic block
+  // a batch made of regular chunks only (the plan kernel counted no other) takes the path written for it
+  if (regular_allowed && __builtin_amdgcn_readfirstlane(cursor[3]) == 0u) {
+    gather_regular_batch<ELEM>(results, pool, pool_chunks, cursor, n_pages, plane_area, lds0, regular_allowed >> 8);
+    return;
+  }
 
   constexpr int R = DS_R;
   constexpr int UNITS = R / 4;
@@ -798,314 +1124,6 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same gather for batches in which EVERY chunk is regular: nothing but whole bit-packed runs, one
-// behind the other at a fixed distance (ids of a high-cardinality column as parquet-java writes them:
-// 504-value runs behind one-byte headers; the plan kernel marks such chunks in their header and counts
-// the others in counter 3 of the call's counter block).  The run of a unit then follows from its index,
-// so the front end of the general kernel (chunk records in LDS, block table, segment search,
-// classification, the list of straddling units, the chunk-end barrier) is not needed: a chunk is its
-// 64-byte header and first segment, read by 18 lanes of every wave two chunks ahead.  The dictionaries
-// are those of more than three quarters per plane (the plan kernel counts chunks of smaller ones with the
-// irregular ones), which makes the sweep eight passes known at compile time: the quarter of an id is kept
-// as two lane masks in scalar registers and a lookup costs no vector instruction; and because no chunk
-// record travels by LDS-DMA, passes 0 and 1 (quarters already resident) need no wait for memory
-// operations, so the stores of the chunk before drain behind them instead of in front of them.
-constexpr int DR_LDS_BYTES = 2 * DS_SLICE_BYTES;
-
-struct RegHead {
-  const PQD_GLOBAL uint32_t* words;  // the page's stream rounded down to a dword
-  uint32_t in_off, max_wi;           // data & 3; largest dword index a 12-byte unit load may start at
-  uint32_t v0, v1, w;
-  uint32_t run_values, run_stride, start0, src0;
-  float rcp_values;
-};
-
-// Dword `lane` of the chunk's header (lanes 0..15) and its first segment (lanes 16, 17).
-__device__ __forceinline__ uint32_t load_chunk_head(const RleSeg* pool, uint32_t chunk, bool valid, uint32_t lane) {
-  const PQD_GLOBAL uint32_t* base = (const PQD_GLOBAL uint32_t*)(pool + (size_t)chunk * SEG_CHUNK);
-  const uint32_t idx = lane < 16u ? (uint32_t)SEG_HEAD_SLOT * 2u + lane : (lane < 18u ? lane - 16u : 0u);
-  return valid ? base[idx] : 0u;  // all zero: an empty chunk
-}
-#define PQD_HEAD_DWORD(hv, i) ((uint32_t)__builtin_amdgcn_readlane((int)(hv), (i)))
-
-__device__ __forceinline__ RegHead read_reg_head(uint32_t hv) {
-  RegHead h;
-  const uint32_t dlo = PQD_HEAD_DWORD(hv, 0), dhi = PQD_HEAD_DWORD(hv, 1);
-  h.in_off = dlo & 3u;
-  h.words = (const PQD_GLOBAL uint32_t*)((((uint64_t)dhi << 32) | dlo) - h.in_off);
-  const uint32_t data_len = PQD_HEAD_DWORD(hv, 8);
-  const uint32_t last_word = data_len ? (h.in_off + data_len - 1u) >> 2 : 0u;
-  h.max_wi = last_word >= 2u ? last_word - 2u : 0u;  // (a regular chunk's page holds at least three dwords)
-  h.v0 = PQD_HEAD_DWORD(hv, 4);
-  h.v1 = PQD_HEAD_DWORD(hv, 5);
-  h.w = PQD_HEAD_DWORD(hv, 7);
-  h.run_values = PQD_HEAD_DWORD(hv, 14);
-  h.run_stride = PQD_HEAD_DWORD(hv, 15);
-  h.start0 = PQD_HEAD_DWORD(hv, 16) >> 2;
-  h.src0 = PQD_HEAD_DWORD(hv, 17);
-  h.rcp_values = 1.0f / (float)(h.run_values ? h.run_values : 1u);
-  return h;
-}
-
-// Issues the 12-byte loads of a regular chunk's units.  meta: bits 0..4 the bit offset inside the first
-// dword loaded, bits 8..9 by how many dwords the load was moved down to stay inside the page.
-// (`valid` false: nothing to fetch; the loads are issued all the same, from `spare`, so that their number is fixed.)
-template <int UNITS>
-__device__ __forceinline__ void fetch_regular(const RegHead& h, bool valid, const void* spare, uint32_t tid, u32x3_a4 (&raw)[UNITS],
-                                              uint32_t (&meta)[UNITS]) {
-  uint32_t wi[UNITS];
-#pragma unroll
-  for (int k = 0; k < UNITS; ++k) {
-    const uint32_t g0 = h.v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-    const uint32_t rel = (g0 < h.v1 ? g0 : h.v0) - h.start0;  // far below 2^24: exact as a float
-    uint32_t q = (uint32_t)((float)rel * h.rcp_values);
-    q -= q * h.run_values > rel ? 1u : 0u;
-    q += (q + 1u) * h.run_values <= rel ? 1u : 0u;
-    const uint32_t byte0 = h.in_off + h.src0 + q * h.run_stride;
-    const uint32_t bitrel = (byte0 & 3u) * 8 + (rel - q * h.run_values) * h.w;
-    const uint32_t w_i = (byte0 >> 2) + (bitrel >> 5);
-    const uint32_t delta = w_i > h.max_wi ? w_i - h.max_wi : 0u;  // the page's last dwords: load what is there
-    wi[k] = valid ? w_i - delta : 0u;
-    meta[k] = (bitrel & 31u) | (delta << 8);
-  }
-  const PQD_GLOBAL uint32_t* words = valid ? h.words : (const PQD_GLOBAL uint32_t*)spare;
-#pragma unroll
-  for (int k = 0; k < UNITS; ++k) raw[k] = *(const PQD_GLOBAL u32x3_a4*)(words + wi[k]);
-}
-
-// One lookup in the quarter QT of a dictionary plane: the quarter of every id is kept as two lane masks
-// (bit 15 and bit 14 of the id, computed once per chunk), one scalar instruction puts the quarter's lanes
-// into EXEC, one 4-byte LDS read fills their result register: no vector arithmetic per lookup.  (All 64
-// lanes of every wave are active around the call.)
-template <int QT>
-__device__ __forceinline__ void mask_lookup(uint32_t& dst, uint32_t addr, uint64_t hi, uint64_t lo) {
-#define PQD_MASK_LOOKUP(SETEXEC) \
-  asm volatile(SETEXEC "\n\tds_read_b32 %0, %1\n\ts_mov_b64 exec, -1" : "+v"(dst) : "v"(addr), "s"(hi), "s"(lo) : "scc")
-  if (QT == 0) PQD_MASK_LOOKUP("s_nor_b64 exec, %2, %3");
-  if (QT == 1) PQD_MASK_LOOKUP("s_andn2_b64 exec, %3, %2");
-  if (QT == 2) PQD_MASK_LOOKUP("s_andn2_b64 exec, %2, %3");
-  if (QT == 3) PQD_MASK_LOOKUP("s_and_b64 exec, %2, %3");
-#undef PQD_MASK_LOOKUP
-}
-
-// Quarter `ps & 3` of plane `ps >> 2` of a four-quarter dictionary into LDS buffer (quarter & 1).
-__device__ __forceinline__ void load_plane_quarter(const uint8_t* slot_base, uint32_t entries, uint32_t ps, uint32_t lds0,
-                                                   uint32_t wave, uint32_t lane) {
-  const uint32_t qt = ps & 3u;
-  const uint32_t n_here = entries - qt * DP_QUARTER_ENTRIES < DP_QUARTER_ENTRIES ? entries - qt * DP_QUARTER_ENTRIES : DP_QUARTER_ENTRIES;
-  load_slice(slot_base + (size_t)(ps >> 2) * DP_PLANE_BYTES + (size_t)qt * DS_SLICE_BYTES, n_here * 4u,
-             lds0 + (qt & 1u) * DS_SLICE_BYTES, wave, lane);
-}
-
-// Pass Q (0..7 in sweep order; DESC: from the last quarter of the high plane down) of the sweep of a
-// four-quarter dictionary.  Passes 0 and 1 find their quarters resident (the sweep before ended with
-// them, in the other direction).  Barriers: none in front of pass 0; for LDS reads in front of pass 1
-// (the quarter of pass 2 is about to overwrite the buffer pass 0 read); a full one from pass 2 on (the
-// quarter requested one pass ago has landed, and everybody is done with the other buffer).
-//   The next chunk's packed dwords are requested in pass PREFETCH_PASS, right behind that pass's quarter
-// request (`prefetch` issues exactly KEEP loads), and the barrier of the pass after it leaves those KEEP
-// loads in flight (the counters are in issue order): requested in front of the sweep they would be
-// waited for at pass 2's barrier, a microsecond later, which is less than a load from HBM takes while
-// the chip is writing.
-constexpr int DR_PREFETCH_PASS = 6;
-template <int R, int Q, bool DESC, int KEEP, typename Prefetch>
-__device__ __forceinline__ void regular_pass(const uint8_t* slot_base, uint32_t entries, uint32_t lds0, uint32_t wave, uint32_t lane,
-                                             uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
-                                             const uint64_t (&mhi)[R], const uint64_t (&mlo)[R], Prefetch prefetch) {
-  constexpr int S = DESC ? 7 - Q : Q;  // plane S >> 2, quarter S & 3
-  constexpr int PL = S >> 2, QT = S & 3;
-  if (Q == 1) wg_barrier_lds();
-  if (Q >= 2 && Q != DR_PREFETCH_PASS + 1) wg_barrier();
-  if (Q >= 2 && Q == DR_PREFETCH_PASS + 1) wg_barrier_keep<KEEP>();
-  if (Q >= 1 && Q + 1 < 8) load_plane_quarter(slot_base, entries, (uint32_t)(DESC ? S - 1 : S + 1), lds0, wave, lane);
-  if (Q == DR_PREFETCH_PASS) prefetch();
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (PL == 0)
-      mask_lookup<QT>(vlo[r], addr[r], mhi[r], mlo[r]);
-    else
-      mask_lookup<QT>(vhi[r], addr[r], mhi[r], mlo[r]);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are invisible to the compiler
-}
-
-template <int R, bool DESC, int KEEP, typename Prefetch>
-__device__ __forceinline__ void regular_sweep(const uint8_t* slot_base, uint32_t entries, uint32_t lds0, uint32_t wave, uint32_t lane,
-                                              uint32_t (&vlo)[R], uint32_t (&vhi)[R], const uint32_t (&addr)[R],
-                                              const uint64_t (&mhi)[R], const uint64_t (&mlo)[R], Prefetch prefetch) {
-  regular_pass<R, 0, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 1, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 2, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 3, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 4, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 5, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 6, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-  regular_pass<R, 7, DESC, KEEP>(slot_base, entries, lds0, wave, lane, vlo, vhi, addr, mhi, mlo, prefetch);
-}
-
-__global__ __launch_bounds__(DS_THREADS) void k_dict_pages_regular8(pqd_page_result* __restrict__ results,
-                                                                    const RleSeg* __restrict__ pool, uint32_t pool_chunks,
-                                                                    const uint32_t* __restrict__ cursor, uint32_t n_pages,
-                                                                    const uint8_t* __restrict__ plane_area) {
-  if (uni(cursor[3]) != 0u) return;  // some chunk is not regular: the general kernel takes the batch
-  extern __shared__ u32x4 lds4[];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(PQD_LDS uint8_t*)reinterpret_cast<uint8_t*>(lds4);
-  constexpr int R = DS_R;
-  constexpr int UNITS = R / 4;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t wave = uni(tid >> 6), lane = tid & 63u;
-
-  uint64_t tag_dict = 0;  // the dictionary whose quarters the LDS buffers hold
-  uint32_t tag_len = 0;
-  bool descending = false;
-
-  // workgroup b takes chunks b, b + grid, b + 2 * grid, ...: at any moment the workgroups of the chip
-  // read and write one window of the batch that moves along (PQD_REGULAR_SHARES: contiguous shares instead)
-  uint32_t n_chunks = n_pages + uni(cursor[0]);
-  if (n_chunks > pool_chunks) n_chunks = pool_chunks;
-  const uint32_t share = (n_chunks + gridDim.x - 1) / gridDim.x;
-#ifdef PQD_REGULAR_SHARES
-  uint32_t chunk = blockIdx.x * share;
-  if (chunk >= n_chunks) return;
-  n_chunks = chunk + share < n_chunks ? chunk + share : n_chunks;  // from here on: the end of this workgroup's share
-  const uint32_t step = 1;
-#else
-  uint32_t chunk = blockIdx.x;
-  if (chunk >= n_chunks) return;
-  const uint32_t step = gridDim.x;
-#endif
-
-  uint32_t hv = load_chunk_head(pool, chunk, true, lane);                             // this chunk
-  uint32_t hv1 = load_chunk_head(pool, chunk + step, chunk + step < n_chunks, lane);  // the next one
-  u32x3_a4 raw[UNITS];
-  uint32_t meta[UNITS];
-  {
-    const RegHead h0 = read_reg_head(hv);
-    // staggered start of long batches over large dictionaries (see the general kernel)
-    if (share >= 16u && PQD_HEAD_DWORD(hv, 11) > DP_QUARTER_ENTRIES) {
-      const uint32_t phase = (blockIdx.x >> 3) & 31u;
-      for (uint32_t i = 0; i < phase; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    fetch_regular<UNITS>(h0, h0.v1 > h0.v0, pool, tid, raw, meta);
-  }
-
-  for (;;) {
-    const RegHead h = read_reg_head(hv);
-    const uint32_t next_chunk = chunk + step;
-    const bool has_next = next_chunk < n_chunks;
-    // the header of the chunk after the next one is requested now; the next chunk's is here already
-    const uint32_t hv2 = load_chunk_head(pool, next_chunk + step, has_next && next_chunk + step < n_chunks, lane);
-    if (h.v1 > h.v0) {  // (uniform over the workgroup; an empty chunk belongs to a page the plan kernel finished or left over)
-      const uint32_t v0 = h.v0, n_out = h.v1;
-      const uint32_t dict_len = PQD_HEAD_DWORD(hv, 11);
-      const uint64_t dict_addr = ((uint64_t)PQD_HEAD_DWORD(hv, 13) << 32) | PQD_HEAD_DWORD(hv, 12);
-      const uint64_t out_addr = ((uint64_t)PQD_HEAD_DWORD(hv, 3) << 32) | PQD_HEAD_DWORD(hv, 2);
-      const uint32_t page = PQD_HEAD_DWORD(hv, 10);
-      const uint32_t slot1 = PQD_HEAD_DWORD(hv, 6) >> 16;
-      const uint32_t entries = dict_len < 65536u ? dict_len : 65536u;  // more than three quarters (the plan kernel saw to it)
-      const uint8_t* slot_base = plane_area + (size_t)(slot1 - 1u) * DP_SLOT_BYTES;
-      if (dict_addr != tag_dict || dict_len != tag_len) {  // first chunk, another dictionary: the two quarters the sweep starts with
-        tag_dict = dict_addr;
-        tag_len = dict_len;
-        wg_barrier();  // nobody still reads the buffers
-        load_plane_quarter(slot_base, entries, descending ? 7u : 0u, lds0, wave, lane);
-        load_plane_quarter(slot_base, entries, descending ? 6u : 1u, lds0, wave, lane);
-        wg_barrier();
-      }
-
-      // ---- 1. ids into registers (their packed dwords were requested one chunk ago)
-      uint32_t id[R];
-      const uint32_t w = h.w;
-#pragma unroll
-      for (int k = 0; k < UNITS; ++k) {
-        uint32_t d0 = raw[k].x, d1 = raw[k].y, d2 = raw[k].z;
-        const uint32_t dl = meta[k] >> 8;
-        if (__builtin_amdgcn_ballot_w64(dl != 0)) {  // rare: a unit in the page's last dwords
-          d0 = dl == 1 ? d1 : (dl == 2 ? d2 : d0);
-          d1 = dl == 1 ? d2 : (dl == 2 ? 0u : d1);
-          d2 = dl == 0 ? d2 : 0u;
-        }
-        const uint32_t b = meta[k] & 31u;
-        const uint32_t lo = funnel_shr(d0, d1, b), hi = funnel_shr(d1, d2, b);
-        id[4 * k] = unit_value(lo, hi, w, 0);
-        id[4 * k + 1] = unit_value(lo, hi, w, 1);
-        id[4 * k + 2] = unit_value(lo, hi, w, 2);
-        id[4 * k + 3] = unit_value(lo, hi, w, 3);
-      }
-
-      // ---- 2. ids beyond the dictionary (see the general kernel)
-      const uint32_t id_bits = (w + 7u) & ~7u;
-      if (id_bits >= 32 || (1u << id_bits) > dict_len) {
-        uint32_t bad = ~0u;
-#pragma unroll
-        for (int k = UNITS - 1; k >= 0; --k) {
-          const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-#pragma unroll
-          for (int j = 3; j >= 0; --j) {
-            const bool over = id[4 * k + j] >= dict_len;
-            bad = (over && g0 + j < n_out) ? g0 + j : bad;
-            id[4 * k + j] = over ? 0u : id[4 * k + j];
-          }
-        }
-        if (bad != ~0u) {  // the plan kernel wrote the page's result; an id beyond the dictionary comes before whatever ended the header walk
-          atomicMin(&results[page].values_written, bad);
-          results[page].status = PQD_DICT_OOB;
-        }
-      }
-
-      // ---- 3. (the next chunk's packed dwords are requested inside the sweep)
-      const RegHead nh = read_reg_head(hv1);
-      auto prefetch = [&]() { fetch_regular<UNITS>(nh, has_next && nh.v1 > nh.v0, pool, tid, raw, meta); };
-
-      // ---- 4. gather: an id's LDS address is (4 * id) & 0x1FFFF in every pass, its quarter two lane masks
-      uint32_t vlo[R], vhi[R];
-      uint64_t mhi[R], mlo[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        vlo[r] = vhi[r] = 0;
-        mhi[r] = __builtin_amdgcn_ballot_w64(id[r] >= 0x8000u);
-        id[r] = (id[r] << 2) & 0x1FFFFu;
-        mlo[r] = __builtin_amdgcn_ballot_w64(id[r] >= 0x10000u);
-      }
-      if (!descending)
-        regular_sweep<R, false, UNITS>(slot_base, entries, lds0, wave, lane, vlo, vhi, id, mhi, mlo, prefetch);
-      else
-        regular_sweep<R, true, UNITS>(slot_base, entries, lds0, wave, lane, vlo, vhi, id, mhi, mlo, prefetch);
-      descending = !descending;
-
-      // ---- 5. store, 16 bytes per lane per instruction
-#pragma unroll
-      for (int k = 0; k < UNITS; ++k) {
-        const uint32_t g0 = v0 + 4 * ((uint32_t)k * DS_THREADS + tid);
-        if (g0 >= n_out) continue;
-        PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)out_addr + g0;
-        if (g0 + 4 <= n_out) {
-          u32x4_a4 r0 = {vlo[4 * k], vhi[4 * k], vlo[4 * k + 1], vhi[4 * k + 1]};
-          u32x4_a4 r1 = {vlo[4 * k + 2], vhi[4 * k + 2], vlo[4 * k + 3], vhi[4 * k + 3]};
-          PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o), r0);
-          PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(o + 2), r1);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (g0 + j < n_out) {
-              u32x2_a4 x = {vlo[4 * k + j], vhi[4 * k + j]};
-              o[j] = x;
-            }
-        }
-      }
-    } else if (has_next) {
-      const RegHead nh = read_reg_head(hv1);
-      fetch_regular<UNITS>(nh, nh.v1 > nh.v0, pool, tid, raw, meta);
-    }
-    if (!has_next) break;
-    hv = hv1;
-    hv1 = hv2;
-    chunk = next_chunk;
-  }
-}
-#undef PQD_HEAD_DWORD
-
 // Per device, set on the first launch there: the number of CUs and the dynamic-LDS attribute of the
 // two kernels (racing first launches write the same values).
 constexpr int DS_MAX_DEVICES = 64;
@@ -1146,8 +1164,6 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dict_pages_sliced<8>), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dict_pages_regular8), hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS_BYTES);
-    if (e != hipSuccess) return e;
     __atomic_store_n(&g_cu_count[dev], prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, __ATOMIC_RELEASE);
   }
   const int cus = __atomic_load_n(&g_cu_count[dev], __ATOMIC_ACQUIRE);
@@ -1158,17 +1174,16 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
 #ifdef PQD_PROF
   if (!g_prof && (e = hipMalloc((void**)&g_prof, 1024 * 24 * 8)) != hipSuccess) return e;
 #endif
-  // Batches of 8-byte dictionary pages made of regular chunks only (counter 3 stays zero) are gathered by
-  // the kernel written for them, and the general kernel then returns at once; both are enqueued because
-  // only the device knows which kind a batch is.  PQD_DICT_REGULAR=0 keeps every batch on the general kernel.
+  // Batches made of regular chunks only (counter 3 stays zero) take the path written for them inside the
+  // kernel; only the device knows which kind a batch is.  PQD_DICT_REGULAR=0 keeps every batch on the general path.
   const char* reg_env = getenv("PQD_DICT_REGULAR");
-  const bool regular = elem == 8 && plane_area != nullptr && !(reg_env && strcmp(reg_env, "0") == 0);
-  if (regular)
-    hipLaunchKernelGGL(k_dict_pages_regular8, dim3(grid), dim3(DS_THREADS), DR_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area);
+  const bool regular = (elem == 4 || plane_area != nullptr) && !(reg_env && strcmp(reg_env, "0") == 0);
+  const char* stg_env = getenv("PQD_DICT_STAGGER");
+  const uint32_t stagger = stg_env ? (uint32_t)atoi(stg_env) : 10u;
   if (elem == 4)
-    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, 0u PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | (stagger << 8) : 0u PROF_ARG);
   else
-    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u : 0u PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | (stagger << 8) : 0u PROF_ARG);
 #ifdef PQD_PROF
   prof_report(grid, stream);
 #endif

@@ -781,8 +781,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.reserved[0] = V;  // marks the chunk as regular: run r0 + i = values start0 + i*V, bytes src0 + i*S
               hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
-              // (k_dict_pages_regular8 takes batches of such chunks over four-quarter dictionaries only)
-              if (elem == 8 && c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + 3, 1u);
+              // (the regular path of k_dict_pages_sliced takes batches of such chunks over four-quarter dictionaries only)
+              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + 3, 1u);
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
               uint32_t packed = 0;
@@ -926,10 +926,10 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         hd->reserved[1] = 0;
       }
       __syncthreads();
-      // Chunks of 8-byte dictionary pages that are nothing but whole bit-packed runs at one distance from
+      // Chunks of dictionary pages that are nothing but whole bit-packed runs at one distance from
       // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
-      // chunks; the others are counted, and a batch without any is gathered by k_dict_pages_regular8.
-      if (want_dict && elem == 8) {
+      // chunks; the others are counted, and a batch without any is gathered by the regular path of k_dict_pages_sliced.
+      if (want_dict) {
         const uint32_t s0 = chunk[0].start4, c0 = chunk[0].src;
         const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
         bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&

@@ -256,6 +256,7 @@ int noalloc_scratch(unsigned char** out) {
 // events per timed call, kept until pqd_phase_ms_mean reads them.
 struct PhaseTimer {
   bool enabled = false;
+  bool gather_only = false;  // record only the two events around the gather launch
   int device = -1;
   std::vector<hipEvent_t> events;  // 4 per call; the first `used` sets are recorded
   size_t used = 0;
@@ -266,6 +267,10 @@ constexpr size_t PHASE_MAX_CALLS = 4096;
 int phase_mark(int i, hipStream_t s) {
   PhaseTimer& t = g_phase;
   if (!t.enabled || t.used >= PHASE_MAX_CALLS) return PQD_OK;
+  if (t.gather_only && i == 3) {  // events 0 and 3 of the set stay unrecorded
+    ++t.used;
+    return PQD_OK;
+  }
   if (i == 0) {
     int dev = 0;
     PQD_HIP(hipGetDevice(&dev));
@@ -281,6 +286,7 @@ int phase_mark(int i, hipStream_t s) {
       t.events.push_back(e);
     }
   }
+  if (t.gather_only && i == 0) return PQD_OK;
   PQD_HIP(hipEventRecord(t.events[t.used * 4 + i], s));
   if (i == 3) ++t.used;
   return PQD_OK;
@@ -455,7 +461,11 @@ int pqd_event_sync(void* ev) {
   return PQD_OK;
 }
 int pqd_set_phase_timing(int enable) {
-  g_phase.enabled = enable != 0;  // pausing keeps what has been recorded
+  PhaseTimer& t = g_phase;
+  if (enable != 0 && t.used != 0 && t.gather_only != (enable == 2))
+    return fail(PQD_BAD_ARG, "pqd_set_phase_timing: read the running series (pqd_phase_ms_mean) before changing the mode");
+  t.enabled = enable != 0;  // pausing keeps what has been recorded
+  if (enable != 0) t.gather_only = enable == 2;
   return PQD_OK;
 }
 
@@ -467,8 +477,9 @@ int pqd_phase_ms_mean(float ms[3], int* n_calls) {
   if (t.used == 0) return PQD_OK;
   double sum[3] = {0, 0, 0};
   for (size_t c = 0; c < t.used; ++c) {
-    PQD_HIP(hipEventSynchronize(t.events[c * 4 + 3]));
+    PQD_HIP(hipEventSynchronize(t.events[c * 4 + (t.gather_only ? 2 : 3)]));
     for (int i = 0; i < 3; ++i) {
+      if (t.gather_only && i != 1) continue;
       float x = 0.f;
       PQD_HIP(hipEventElapsedTime(&x, t.events[c * 4 + i], t.events[c * 4 + i + 1]));
       sum[i] += x;
