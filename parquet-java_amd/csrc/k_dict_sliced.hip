@@ -813,10 +813,11 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(PQD_LDS uint8_t*)lds;  // LDS byte address of the dynamic block
   // a batch made of regular chunks only (the plan kernel counted no other) takes the path written for it
-  if (regular_allowed && __builtin_amdgcn_readfirstlane(cursor[3]) == 0u) {
+  if ((regular_allowed & 1u) && __builtin_amdgcn_readfirstlane(cursor[3]) == 0u) {
     gather_regular_batch<ELEM>(results, pool, pool_chunks, cursor, n_pages, plane_area, lds0, regular_allowed >> 8);
     return;
   }
+  if (regular_allowed & 2u) return;  // PQD_DICT_REGULAR=only (tests): nothing but the regular path may write
 
   constexpr int R = DS_R;
   constexpr int UNITS = R / 4;
@@ -1178,12 +1179,13 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
   // kernel; only the device knows which kind a batch is.  PQD_DICT_REGULAR=0 keeps every batch on the general path.
   const char* reg_env = getenv("PQD_DICT_REGULAR");
   const bool regular = (elem == 4 || plane_area != nullptr) && !(reg_env && strcmp(reg_env, "0") == 0);
+  const uint32_t regular_only = reg_env && strcmp(reg_env, "only") == 0 ? 2u : 0u;  // (tests: the general path stays idle)
   const char* stg_env = getenv("PQD_DICT_STAGGER");
   const uint32_t stagger = stg_env ? (uint32_t)atoi(stg_env) : 10u;
   if (elem == 4)
-    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | (stagger << 8) : 0u PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | regular_only | (stagger << 8) : 0u PROF_ARG);
   else
-    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | (stagger << 8) : 0u PROF_ARG);
+    hipLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | regular_only | (stagger << 8) : 0u PROF_ARG);
 #ifdef PQD_PROF
   prof_report(grid, stream);
 #endif

@@ -664,3 +664,67 @@ def test_eight_byte_dictionaries_of_every_size_class(gpu, orc, monkeypatch, slot
         assert st == 0 and written == want.size
         assert (out.view(np.int64) == want).all()
         assert (guard == 0xA5).all()
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+@pytest.mark.parametrize("mode", ["only", "0"])
+def test_dictionary_batches_of_regular_chunks(gpu, orc, monkeypatch, elem, mode):
+    """Batches in which every chunk is nothing but whole bit-packed runs at one distance (non-repeating ids as
+    parquet-java writes them) over dictionaries of more than 49152 entries take a path of their own inside
+    the sliced gather.  PQD_DICT_REGULAR=only lets nothing else write (a batch that did not qualify would
+    come back unwritten), =0 keeps the general path: both must give the oracle's values.  Page lengths that
+    end inside a unit, span chunks (the second chunk begins inside a run), take the bulk plan path or are a
+    single run; narrow ids over a large dictionary; several dictionaries and an empty page in one call;
+    dictionaries that end inside the last quarter, with an id beyond them."""
+    import parquet_java_amd as pq
+    monkeypatch.setenv("PQD_DICT_PATH", "sliced")
+    monkeypatch.setenv("PQD_DICT_REGULAR", mode)
+    dt = np.int32 if elem == 4 else np.int64
+    rng = np.random.default_rng(4100 + elem)
+
+    def non_repeating(n, reach):
+        ids = rng.integers(0, reach, n).astype(np.int32)
+        same = np.flatnonzero(ids[1:] == ids[:-1]) + 1  # no two equal neighbours: the encoder never sees 8 repeats
+        ids[same] = (ids[same] + 1) % reach
+        return ids
+
+    pages, expect = [], []
+    for n_dict in (65536, 49153, 57000, 70000):
+        dic = rng.integers(-(1 << 31), 1 << 31, n_dict).astype(dt)
+        if elem == 8:
+            dic = dic * np.int64(0x100000001) + 7
+        reach = min(n_dict, 65536)
+        for n in (20000, 19997, 504 * 7, 1000, 8, 3, 40000, 100_000, 0):
+            ids = non_repeating(n, reach)
+            if n >= 16:
+                ids[:8] = [0, reach - 1, 16383, 16384, 32767, 32768, 49151, 49152]
+            data = orc.dict_encode_ids(ids, n_dict) if n else np.array([16], np.uint8)
+            pages.append(gpu.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            expect.append((0, dic[ids]))
+        for w in (3, 10, 13):  # pages written while the dictionary was still small
+            ids = non_repeating(20000, 1 << w)
+            data = np.concatenate([np.array([w], np.uint8), orc.rle_encode(w, ids)])
+            pages.append(gpu.Page(data, ids.size, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            expect.append((0, dic[ids]))
+        if n_dict < 65536:  # ids of 16 bits can point beyond such a dictionary
+            ids = non_repeating(20000, n_dict)
+            ids[12345] = n_dict + 5
+            ids[15000] = 65535
+            data = orc.dict_encode_ids(ids, n_dict)
+            pages.append(gpu.Page(data, ids.size, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            ost, ovals = orc.dict_decode(data, dic, ids.size)
+            assert ost == pq.DICT_OOB and ovals.size == 12345
+            expect.append((ost, ovals))
+    res = gpu.decode_pages(pages)
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(res, expect)):
+        assert st == ost and written == ovals.size, (i, st, written, ost, ovals.size)
+        assert (out.view(dt)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all(), i
+    if mode == "only":  # the switch does what the test relies on: a batch with one irregular chunk is not written at all
+        dic = rng.integers(-(1 << 31), 1 << 31, 65536).astype(dt)
+        ids = non_repeating(20000, 65536)
+        ids[5000:5100] = 77  # an RLE run
+        bad = [gpu.Page(orc.dict_encode_ids(non_repeating(20000, 65536), 65536), 20000, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic),
+               gpu.Page(orc.dict_encode_ids(ids, 65536), 20000, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic)]
+        for st, written, _, out, guard in gpu.decode_pages(bad):
+            assert st == 0 and written == 20000 and (out == 0xA5).all()
