@@ -18,6 +18,7 @@
 // HBM-bound: w/8 bytes in + elem bytes out per value; the dictionary is read through L2.
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
+#include "pqd_expand.hpp"
 #include "pqd_rle_plan.hpp"
 
 namespace pqd {
@@ -234,8 +235,8 @@ __device__ void rle_scan_window(RleState& st, const uint32_t* win, const uint8_t
 
 // One page, decoded by the whole workgroup.
 template <int ELEM, bool HAS_DICT>
-__device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_result* __restrict__ results, uint32_t page) {
-  __shared__ u32x4 win4[WINDOW_PIECES];
+__device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_result* __restrict__ results, uint32_t page,
+                         u32x4* win4) {  // win4: WINDOW_PIECES pieces of LDS, declared by the kernel
   __shared__ uint32_t seg_start[MAX_SEGS + 1];
   __shared__ uint32_t seg_src[MAX_SEGS];
   __shared__ uint32_t seg_kind[MAX_SEGS];
@@ -417,38 +418,55 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
 
 // Without a plan array: workgroup b decodes page b.  With one: only the pages the planned path could
 // not take are decoded here; the plan kernel has listed them (entry i of the list sits in
-// only_fallback[i].fallback_page, their number in *fallback_count), and a small grid strides over the list.
+// only_fallback[i].fallback_page, their number in *fallback_count), and the grid strides over the list.
+// Dictionary pages with a plan: the same launch then expands the short chunks the sliced gather leaves
+// aside (pool != nullptr; pqd_expand.hpp), in the LDS the page decoder used.
 template <int ELEM, bool HAS_DICT>
 __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
                                                            pqd_page_result* __restrict__ results,
                                                            uint32_t n_pages,
                                                            const RlePagePlan* __restrict__ only_fallback,
-                                                           const uint32_t* __restrict__ fallback_count) {
+                                                           const uint32_t* __restrict__ fallback_count,
+                                                           const RleSeg* __restrict__ pool, uint32_t pool_chunks,
+                                                           const uint32_t* __restrict__ cursor) {
+  __shared__ u32x4 win4[WINDOW_PIECES];
+  static_assert(sizeof(u32x4) * WINDOW_PIECES >= sizeof(RleSeg) * SEG_CHUNK + 4 * (2 * EX_THREADS * EX_UNITS + 2), "the window holds the expansion's LDS");
+  static_assert(RLE_THREADS == EX_THREADS, "one workgroup shape for both parts");
   if (!only_fallback) {
-    if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x);
+    if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x, win4);
     return;
   }
   uint32_t n = *fallback_count;
   if (n > n_pages) n = n_pages;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint32_t page = only_fallback[i].fallback_page;
-    if (page < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, page);
+    if (page < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
     __syncthreads();  // the next page reuses the LDS
+  }
+  if constexpr (HAS_DICT) {
+    if (pool) {
+      RleSeg* cs_buf = reinterpret_cast<RleSeg*>(win4);
+      uint32_t* slow_list = reinterpret_cast<uint32_t*>(cs_buf + SEG_CHUNK);
+      dict_expand_direct_chunks<ELEM>(results, pool, pool_chunks, cursor, cs_buf, slow_list, slow_list + 2 * EX_THREADS * EX_UNITS);
+    }
   }
 }
 
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
-                            hipStream_t stream) {
+                            hipStream_t stream, const void* pool, uint32_t pool_chunks, const uint32_t* cursor) {
   if (n_pages == 0) return hipSuccess;
   const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
-  const dim3 grid(pl && n_pages > 512u ? 512u : n_pages), block(RLE_THREADS);
+  const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
+  // with a plan: a grid that strides over the left-over pages (few) and, for dictionary pages, over the direct chunks
+  const uint32_t cap = has_dict && sp ? 1024u : 512u;
+  const dim3 grid(pl && n_pages > cap ? cap : n_pages), block(RLE_THREADS);
   if (!has_dict)
-    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
+    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
   else if (elem == 4)
-    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
+    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
   else
-    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count);
+    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
   return hipGetLastError();
 }
 

@@ -13,6 +13,8 @@
 // runs, so one such round brings in every remaining header of the page; irregular pages simply
 // take more rounds.  Latency-bound by design: the chip hides it by running one wave per page for
 // every page of the batch at once.
+#include <cstdlib>
+
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 #include "pqd_rle_plan.hpp"
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                                                                   RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
                                                                   uint32_t n_pages, int want_dict, int elem,
-                                                                  DictPlanes planes, int small_ran) {
+                                                                  DictPlanes planes, int small_ran, uint32_t direct_max) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   }
   __syncthreads();
 
+  const uint32_t tail_chunks = pool_chunks > n_pages ? pool_chunks - n_pages : 0u;  // the pool behind the page slots
   const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
   uint32_t v0 = 0;  // start of the chunk being collected
   uint32_t emitted = 0;  // chunks written for this page
@@ -720,14 +723,15 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       const uint32_t vreg = reg * V;
       const uint32_t n_bulk = sp ? vreg / sp : 0u;
       if (n_bulk >= 2) {
-        if (tid == 0) st.chunk_slot = atomicAdd(cursor, n_bulk - 1u);
+        if (tid == 0) {
+          // (a request that is not granted takes nothing; it only makes the tail look fuller to later requests)
+          const uint32_t asked = atomicAdd(cursor + PLAN_CTR_REQUESTS, n_bulk - 1u);
+          st.chunk_slot = page < pool_chunks && (uint64_t)asked + (n_bulk - 1u) <= tail_chunks ? atomicAdd(cursor + PLAN_CTR_TAIL, n_bulk - 1u) : ~0u;
+        }
         __syncthreads();
         const uint32_t tail0 = n_pages + st.chunk_slot;  // chunks 1.. of this page; chunk 0 sits at the page's own slot
-        if (page >= pool_chunks || (uint64_t)tail0 + (n_bulk - 1u) > pool_chunks) {
-          // the pool is too small for this page: the slots taken must still read as chunks
-          for (uint32_t c = 1 + tid; c < n_bulk; c += PLAN_THREADS)
-            if (tail0 + c - 1 < pool_chunks) write_empty_chunk(pool, tail0 + c - 1, page);
-          fallback = true;
+        if (st.chunk_slot == ~0u) {
+          fallback = true;  // the pool is too small for this page
         } else {
           // The expansion kernel reads only the first segment and the header of a regular chunk: for
           // plain hybrid pages every lane writes whole chunks.  The dictionary kernel has no such path
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
               // (the regular path of k_dict_pages_sliced takes batches of such chunks over four-quarter dictionaries only)
-              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + 3, 1u);
+              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + PLAN_CTR_IRREGULAR, 1u);
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
               uint32_t packed = 0;
@@ -894,11 +898,22 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         }
         k = hi;
       }
+      // short chunks over a dictionary that is swept go to k_dict_expand: they are taken from the pool's end
+      const bool direct = want_dict && v1 - v0 <= direct_max &&
+                          (elem == 8 ? d.dict_len > DP_QUARTER_ENTRIES : (uint64_t)d.dict_len * 4u > 2ull * DS_SLICE_BYTES);
       if (tid == 0) {
         // the first chunk of page p is pool chunk p (thousands of pages asking one counter for a slot
         // at the same time would queue up behind each other); further chunks come from the shared tail
-        uint32_t slot = emitted == 0 ? page : n_pages + atomicAdd(cursor, 1u);
-        st.chunk_slot = slot < pool_chunks ? slot : ~0u;
+        uint32_t slot = ~0u;
+        if (page >= pool_chunks) {
+          // no room for this page at all
+        } else if (emitted == 0 && !direct) {
+          slot = page;
+        } else if (atomicAdd(cursor + PLAN_CTR_REQUESTS, 1u) < tail_chunks) {
+          slot = direct ? pool_chunks - 1u - atomicAdd(cursor + PLAN_CTR_DIRECT, 1u) : n_pages + atomicAdd(cursor + PLAN_CTR_TAIL, 1u);
+          if (direct && emitted == 0) write_empty_chunk(pool, page);  // the sliced kernel finds nothing at the page's slot
+        }
+        st.chunk_slot = slot;
       }
       __syncthreads();
       const uint32_t slot = st.chunk_slot;
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       // Chunks of dictionary pages that are nothing but whole bit-packed runs at one distance from
       // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
       // chunks; the others are counted, and a batch without any is gathered by the regular path of k_dict_pages_sliced.
-      if (want_dict) {
+      if (want_dict && !direct) {
         const uint32_t s0 = chunk[0].start4, c0 = chunk[0].src;
         const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
         bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
             hd->reserved[0] = V;
             hd->reserved[1] = S;
           } else {
-            atomicAdd(cursor + 3, 1u);
+            atomicAdd(cursor + PLAN_CTR_IRREGULAR, 1u);
           }
         }
       }
@@ -1020,13 +1035,16 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
   if (want_dict && elem == 8 && planes.n_slots != 0)
     hipLaunchKernelGGL(k_dict_slots, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, descs, n_pages, cursor, planes);
   const bool small = try_small && !want_dict && elem == 4;
+  // PQD_DIRECT_MAX: chunks of dictionary pages of at most that many values are gathered from memory (0: none)
+  const char* dm = getenv("PQD_DIRECT_MAX");
+  const uint32_t direct_max = dm ? (uint32_t)atoi(dm) : DS_DIRECT_MAX;
   if (small) {  // small pages first: what it decodes the plan kernel skips
     hipError_t e = launch_rle_small_pages(descs, results, plans, n_pages, stream);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
                      reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
-                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0);
+                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0, direct_max);
   return hipGetLastError();
 }
 

@@ -619,7 +619,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if ((st = phase_mark(1, s))) return st;
         PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, planes.area, s));
         if ((st = phase_mark(2, s))) return st;
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s, ps.gen_pool, pool_chunks, ps.counters));
         if ((st = phase_mark(3, s))) return st;
       }
       return PQD_OK;
@@ -703,7 +703,7 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
     PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, planes.area, s));
   } else
     PQD_HIP(pqd::launch_rle_expand(pool, pool_chunks, counters, n_pages, s));
-  PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s));
+  PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s, dict ? pool : nullptr, pool_chunks, counters));
   return PQD_OK;
 }
 

@@ -16,9 +16,12 @@ hipError_t launch_unpack_run_i64(const uint8_t* in, uint64_t in_bytes, int64_t* 
 // elem: 4 or 8; has_dict: PQD_ENC_RLE_DICTIONARY pages
 // only_fallback_plans: nullptr = decode every page; else decode only pages whose plan is flagged for fallback
 // (the plan kernel lists those pages: entry i in plans[i].fallback_page, their number in *fallback_count)
+// (pool / pool_chunks / cursor: planned dictionary pages only: the same launch expands the short chunks that the
+// plan kernel took from the pool's end, DS_DIRECT_MAX in pqd_rle_plan.hpp, looking their ids up in memory)
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
-                            hipStream_t stream);
+                            hipStream_t stream, const void* pool = nullptr, uint32_t pool_chunks = 0,
+                            const uint32_t* cursor = nullptr);
 // header walk of hybrid pages (plain ones, or dictionary pages with want_dict) -> chunks of run
 // segments in `pool` (pqd_rle_plan.hpp): `plans` holds n_pages RlePagePlan records, `pool` pool_chunks
 // chunks, `cursor` two zeroed counters (chunks taken from the pool's shared tail; pages left to the

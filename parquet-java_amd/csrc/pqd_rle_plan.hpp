@@ -58,6 +58,24 @@ struct RleChunkHead {
 };
 static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
 
+// Dictionary pages: a chunk of at most DS_DIRECT_MAX values over a dictionary that would have to be swept through
+// LDS is not gathered by the sliced kernel (a sweep costs the same whatever the chunk holds, about 10 us of a CU) but
+// by k_dict_expand, which reads the dictionary from memory (a cache line per value at most): run-heavy pages, which
+// are cut into several chunks of a few thousand values (a chunk holds 231 segments), and small pages.  Such chunks
+// are taken from the END of the pool (the last one first), so the sliced kernel never sees them; if it is a page's
+// first chunk, the page's own slot holds an empty chunk.
+constexpr uint32_t DS_DIRECT_MAX = 8192;
+
+// The call's counter block (32-bit counters, zeroed per call):
+//   0  chunks taken from the front of the pool's shared tail (behind the n_pages page slots)
+//   1  pages left to the generic kernel (their list: RlePagePlan::fallback_page)
+//   2  plane slots claimed in this call (DictPlanes::list)
+//   3  dictionary chunks that are not regular (0: the batch takes the regular path of k_dict_pages_sliced)
+//   4  chunks taken from the end of the pool (k_dict_expand's)
+//   5  requests for chunks of the shared tail, granted or not (front and end together never exceed it)
+constexpr int PLAN_CTR_TAIL = 0, PLAN_CTR_FALLBACK = 1, PLAN_CTR_PLANES = 2, PLAN_CTR_IRREGULAR = 3, PLAN_CTR_DIRECT = 4,
+              PLAN_CTR_REQUESTS = 5;
+
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
 constexpr uint32_t PLAN_F_SMALL_DONE = 4u;  // decoded by k_rle_small_pages before the plan kernel ran (which turns it into PLAN_F_DONE)
 constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel

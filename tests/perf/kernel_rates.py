@@ -159,6 +159,10 @@ def main():
               lambda r: orc.dict_encode_ids(np.minimum(r.zipf(1.1, 20000) - 1, 65535).astype(np.int32), 65536), 5000, 20000,
               pq.ENC_RLE_DICTIONARY, 8, dictionary=dic)
 
+    run_pages("dictionary INT64, 65536 entries, small pages: 20000 x 5000",
+              lambda r: orc.dict_encode_ids(r.integers(0, 65536, 5000).astype(np.int32), 65536), 20000, 5000,
+              pq.ENC_RLE_DICTIONARY, 8, dictionary=dic)
+
     def sorted_runs(r):
         x = np.sort(r.integers(0, 65536, 600)).repeat(r.integers(1, 70, 600))[:20000].astype(np.int32)
         return orc.dict_encode_ids(np.concatenate([x, np.full(20000 - x.size, x[-1], np.int32)]), 65536)

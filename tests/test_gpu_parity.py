@@ -728,3 +728,51 @@ def test_dictionary_batches_of_regular_chunks(gpu, orc, monkeypatch, elem, mode)
                gpu.Page(orc.dict_encode_ids(ids, 65536), 20000, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic)]
         for st, written, _, out, guard in gpu.decode_pages(bad):
             assert st == 0 and written == 20000 and (out == 0xA5).all()
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+@pytest.mark.parametrize("direct_max", ["8192", "0", "3000"])
+@pytest.mark.parametrize("pool", [None, "9"])
+def test_dictionary_short_chunks_gathered_from_memory(gpu, orc, monkeypatch, elem, direct_max, pool):
+    """Chunks of at most PQD_DIRECT_MAX values (default 8192) over a dictionary that would have to be swept through
+    LDS are taken from the end of the chunk pool and expanded by the left-over kernel, which reads the dictionary
+    from memory: run-heavy pages (cut into several chunks of a few thousand values), small pages, a page's last
+    chunk.  With the switch at 0 everything goes through the sliced gather; with a pool of 9 chunks most pages
+    find no room and are decoded by the generic kernel.  All must give the oracle's values, ids beyond the
+    dictionary included."""
+    import parquet_java_amd as pq
+    monkeypatch.setenv("PQD_DICT_PATH", "sliced")
+    monkeypatch.setenv("PQD_DIRECT_MAX", direct_max)
+    if pool is not None:
+        monkeypatch.setenv("PQD_POOL_CHUNKS", pool)
+    dt = np.int32 if elem == 4 else np.int64
+    rng = np.random.default_rng(5200 + elem)
+    n_dict = 65536
+    dic = rng.integers(-(1 << 31), 1 << 31, n_dict).astype(dt)
+    if elem == 8:
+        dic = dic * np.int64(0x100000001) - 11
+    short = rng.integers(-(1 << 31), 1 << 31, 40000).astype(dt)  # 16-bit ids can point beyond this one
+    pages, expect = [], []
+
+    def add(ids, d):
+        data = orc.dict_encode_ids(ids, d.size)
+        pages.append(gpu.Page(data, ids.size, pq.ENC_RLE_DICTIONARY, elem, dictionary=d))
+        expect.append(orc.dict_decode(data, d, ids.size))
+
+    for n in (5000, 20000, 8192, 8193, 100, 7):  # small pages and the last chunk of longer ones
+        add(rng.integers(0, n_dict, n).astype(np.int32), dic)
+    for _ in range(4):  # run-heavy pages: several chunks each
+        x = np.sort(rng.integers(0, n_dict, 600)).repeat(rng.integers(1, 70, 600))[:20000].astype(np.int32)
+        add(x, dic)
+    x = np.repeat(rng.integers(0, n_dict, 3000), rng.integers(1, 20, 3000))[:30000].astype(np.int32)  # short runs, unsorted
+    add(x, dic)
+    ids = rng.integers(0, short.size, 6000).astype(np.int32)
+    ids[4321] = 50000  # beyond the dictionary, inside a short chunk
+    add(ids, short)
+    x = np.sort(rng.integers(0, short.size, 500)).repeat(rng.integers(1, 80, 500))[:20000].astype(np.int32)
+    x[15000:15010] = 65535
+    add(x, short)
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(gpu.decode_pages(pages), expect)):
+        assert st == ost and written == ovals.size, (i, st, written, ost, ovals.size)
+        assert (out.view(dt)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all(), i
