@@ -330,16 +330,17 @@ def main():
     # ---- outside the timed region: the other shapes of this workload, for the record
     extras = {}
     if rank == 0:
-        spoiler = torch.zeros(512 << 20, dtype=torch.uint8, device=device)
+        spoiler = torch.zeros(64 << 20, dtype=torch.int64, device=device)
         def timed(fn, iters=10):  # noqa: E306
-            """Mean time of fn() by events around every call, with 1 GiB of unrelated traffic between the calls:
-            a loop over one call alone can find its input still in the 256 MiB Infinity Cache."""
+            """Mean time of fn() by events around every call, with a read of 512 MiB of unrelated data between the
+            calls: a loop over one call alone can find its input still in the 256 MiB Infinity Cache.  (Read-only:
+            dirty lines left in the caches would be written back on the timed call's account.)"""
             fn()
             torch.cuda.synchronize()
             total = 0.0
             a, b = Event(), Event()
             for _ in range(iters):
-                spoiler.add_(1)
+                spoiler.sum()
                 a.record(stream)
                 fn()
                 b.record(stream)

@@ -517,10 +517,11 @@ __device__ __forceinline__ RegHead read_reg_head(uint32_t hv) {
   const uint32_t data_len = PQD_HEAD_DWORD(hv, 8);
   const uint32_t last_word = data_len ? (h.in_off + data_len - 1u) >> 2 : 0u;
   h.max_wi = last_word >= 2u ? last_word - 2u : 0u;  // (a regular chunk's page holds at least three dwords)
-  h.v0 = PQD_HEAD_DWORD(hv, 4);
-  h.v1 = PQD_HEAD_DWORD(hv, 5);
-  h.w = PQD_HEAD_DWORD(hv, 7);
   h.run_values = PQD_HEAD_DWORD(hv, 14);
+  // (a chunk that is not regular is one of the few the plan kernel listed for the left-over launch: it reads as empty)
+  h.v0 = h.run_values ? PQD_HEAD_DWORD(hv, 4) : 0u;
+  h.v1 = h.run_values ? PQD_HEAD_DWORD(hv, 5) : 0u;
+  h.w = PQD_HEAD_DWORD(hv, 7);
   h.run_stride = PQD_HEAD_DWORD(hv, 15);
   h.start0 = PQD_HEAD_DWORD(hv, 16) >> 2;
   h.src0 = PQD_HEAD_DWORD(hv, 17);

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
     if (pool) {
       RleSeg* cs_buf = reinterpret_cast<RleSeg*>(win4);
       uint32_t* slow_list = reinterpret_cast<uint32_t*>(cs_buf + SEG_CHUNK);
-      dict_expand_direct_chunks<ELEM>(results, pool, pool_chunks, cursor, cs_buf, slow_list, slow_list + 2 * EX_THREADS * EX_UNITS);
+      dict_expand_direct_chunks<ELEM>(results, pool, pool_chunks, n_pages, cursor, cs_buf, slow_list, slow_list + 2 * EX_THREADS * EX_UNITS);
     }
   }
 }

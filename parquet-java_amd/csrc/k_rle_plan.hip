@@ -565,6 +565,18 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     return;
   }
 
+  // The page's first eight bytes (prefix and first run header) and the first probe of the plane-slot table are
+  // requested together, before anything waits: a page is planned by one wave, and every dependent trip to
+  // memory is a microsecond of the kernel.
+  uint32_t first8[2] = {0u, 0u};
+  const bool have8 = d.data_len >= 8u && d.data != nullptr;
+  if (have8) __builtin_memcpy(first8, d.data, 8);
+  const bool probe_early = want_dict && elem == 8 && planes.n_slots != 0 && d.dict_len != 0;
+  const uint64_t key_early = probe_early ? dict_plane_key(d.dict, d.dict_len) : 0ull;
+  const uint32_t h_early = probe_early ? dict_plane_hash(key_early, planes.n_slots) : 0u;
+  const uint64_t cur_early = probe_early ? planes.keys[h_early] : 0ull;
+  const uint64_t first64 = ((uint64_t)first8[1] << 32) | first8[0];
+
   // ---- validation and stream prefixes (same rules as the generic kernel)
   int32_t early = PQD_OK;
   bool finished = false;
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       early = n_values ? PQD_DECODE : PQD_OK;
       finished = true;
     } else {
-      w = d.data[0];
+      w = have8 ? (uint32_t)(first64 & 0xFFu) : d.data[0];
       pos = 1;
     }
   } else if (d.flags & PQD_F_LENGTH_PREFIX) {
@@ -587,8 +599,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       early = PQD_EOF;
       finished = true;
     } else {
-      const uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) |
-                           ((uint32_t)d.data[3] << 24);
+      const uint32_t len = have8 ? (uint32_t)first64
+                                 : (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) | ((uint32_t)d.data[3] << 24);
       if ((int32_t)len < 0) {
         early = PQD_DECODE;
         finished = true;
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     uint32_t h = dict_plane_hash(key, planes.n_slots);
     const uint32_t probes = planes.n_slots < DP_MAX_PROBES ? planes.n_slots : DP_MAX_PROBES;
     for (uint32_t i = 0; i < probes && slot1 == 0; ++i) {
-      const uint64_t cur = planes.keys[h];
+      const uint64_t cur = i == 0 && probe_early ? cur_early : planes.keys[h];
       if (cur == key) slot1 = h + 1u;
       if (cur == 0ull) break;  // a free entry ends the probe sequence: the dictionary has no slot
       h = h + 1u == planes.n_slots ? 0u : h + 1u;
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   }
   __syncthreads();
 
-  const uint32_t tail_chunks = pool_chunks > n_pages ? pool_chunks - n_pages : 0u;  // the pool behind the page slots
+  const uint32_t front_limit = plan_front_limit(pool_chunks, n_pages, want_dict != 0);  // slots below it: page slots + front of the tail
   const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
   uint32_t v0 = 0;  // start of the chunk being collected
   uint32_t emitted = 0;  // chunks written for this page
@@ -688,7 +700,10 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   // What remains of the page (the last runs, anything irregular) goes through the loop below.
   if (w > 0 && (uint64_t)pos + 16 <= end) {
     uint32_t hx;
-    __builtin_memcpy(&hx, d.data + pos, 4);
+    if (have8 && pos <= 4)
+      hx = (uint32_t)(first64 >> (8 * pos));
+    else
+      __builtin_memcpy(&hx, d.data + pos, 4);
     uint32_t header, nb;
     varint_of_dword(hx, header, nb);
     const uint32_t g0 = header >> 1;
@@ -699,6 +714,10 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       uint32_t rmax = (end - pos) / S;  // runs wholly inside the stream ...
       if (n_values / V < rmax) rmax = n_values / V;  // ... all of whose values are wanted
       uint32_t reg = rmax;  // leading runs with exactly that header
+      // the header of the run behind the prefix, should all rmax runs turn out equal (requested with the checks below)
+      const uint64_t p2_guess = (uint64_t)pos + (uint64_t)rmax * S;
+      uint32_t hx2_guess = 0;
+      if (p2_guess + 4 <= end) __builtin_memcpy(&hx2_guess, d.data + p2_guess, 4);
       for (uint32_t base = 0; base < rmax; base += 64u * BULK_LOADS) {
         uint32_t x[BULK_LOADS];
 #pragma unroll
@@ -723,15 +742,14 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       const uint32_t vreg = reg * V;
       const uint32_t n_bulk = sp ? vreg / sp : 0u;
       if (n_bulk >= 2) {
-        if (tid == 0) {
-          // (a request that is not granted takes nothing; it only makes the tail look fuller to later requests)
-          const uint32_t asked = atomicAdd(cursor + PLAN_CTR_REQUESTS, n_bulk - 1u);
-          st.chunk_slot = page < pool_chunks && (uint64_t)asked + (n_bulk - 1u) <= tail_chunks ? atomicAdd(cursor + PLAN_CTR_TAIL, n_bulk - 1u) : ~0u;
-        }
+        if (tid == 0) st.chunk_slot = atomicAdd(cursor + PLAN_CTR_TAIL, n_bulk - 1u);
         __syncthreads();
         const uint32_t tail0 = n_pages + st.chunk_slot;  // chunks 1.. of this page; chunk 0 sits at the page's own slot
-        if (st.chunk_slot == ~0u) {
-          fallback = true;  // the pool is too small for this page
+        if (page >= front_limit || (uint64_t)tail0 + (n_bulk - 1u) > front_limit) {
+          // the pool is too small for this page: the slots taken must still read as chunks
+          for (uint32_t c = 1 + tid; c < n_bulk; c += PLAN_THREADS)
+            if (tail0 + c - 1 < front_limit) write_empty_chunk(pool, tail0 + c - 1, page);
+          fallback = true;
         } else {
           // The expansion kernel reads only the first segment and the header of a regular chunk: for
           // plain hybrid pages every lane writes whole chunks.  The dictionary kernel has no such path
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
               // (the regular path of k_dict_pages_sliced takes batches of such chunks over four-quarter dictionaries only)
-              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) atomicAdd(cursor + PLAN_CTR_IRREGULAR, 1u);
+              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) cursor[PLAN_CTR_IRREGULAR] = 1u  /* a flag, not a count: thousands of atomics on one word queue up behind each other */;
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
               uint32_t packed = 0;
@@ -839,7 +857,10 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       const uint64_t p2 = (uint64_t)pos + (uint64_t)reg * S;
       if (prefix_staged && vreg < n_values && p2 + 4 <= end) {
         uint32_t hx2, header2, nb2;
-        __builtin_memcpy(&hx2, d.data + p2, 4);
+        if (p2 == p2_guess)
+          hx2 = hx2_guess;
+        else
+          __builtin_memcpy(&hx2, d.data + p2, 4);
         varint_of_dword(hx2, header2, nb2);
         const uint32_t g2 = header2 >> 1;
         const uint32_t ns = st.nstage;
@@ -900,18 +921,44 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       }
       // short chunks over a dictionary that is swept go to k_dict_expand: they are taken from the pool's end
       const bool direct = want_dict && v1 - v0 <= direct_max &&
-                          (elem == 8 ? d.dict_len > DP_QUARTER_ENTRIES : (uint64_t)d.dict_len * 4u > 2ull * DS_SLICE_BYTES);
+                    (elem == 8 ? d.dict_len > DP_QUARTER_ENTRIES : (uint64_t)d.dict_len * 4u > 2ull * DS_SLICE_BYTES);
+      // Chunks of dictionary pages that are nothing but whole bit-packed runs at one distance from
+      // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
+      // chunks; a batch without any other chunk is gathered by the regular path of k_dict_pages_sliced.
+      bool regular = false;
+      uint32_t V = 1u << 20, S = 0;  // a single run: every unit lies in run 0
+      if (want_dict && !direct) {
+        const uint32_t s0 = stage[0].start4, c0 = stage[0].src;
+        const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
+        bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
+                  d.dict_len > 3u * DP_QUARTER_ENTRIES;  // (that path sweeps four quarters per plane)
+        if (k >= 2) {
+          V = (stage[1].start4 >> 2) - (s0 >> 2);
+          S = stage[1].src - c0;
+          ok = ok && V != 0 && (V & 3u) == 0 && V <= (1u << 20);
+        }
+        bool bad = false;
+        for (uint32_t i = tid; i < k; i += PLAN_THREADS)
+          bad = bad || stage[i].start4 != s0 + ((i * V) << 2) || stage[i].src != c0 + i * S;
+        regular = ok && __builtin_amdgcn_ballot_w64(bad) == 0;
+      }
       if (tid == 0) {
         // the first chunk of page p is pool chunk p (thousands of pages asking one counter for a slot
         // at the same time would queue up behind each other); further chunks come from the shared tail
         uint32_t slot = ~0u;
-        if (page >= pool_chunks) {
+        if (page >= front_limit) {
           // no room for this page at all
-        } else if (emitted == 0 && !direct) {
+        } else if (direct) {
+          const uint32_t b = atomicAdd(cursor + PLAN_CTR_DIRECT, 1u);
+          if (b < pool_chunks - front_limit) {
+            slot = pool_chunks - 1u - b;
+            if (emitted == 0) write_empty_chunk(pool, page);  // the sliced kernel finds nothing at the page's slot
+          }
+        } else if (emitted == 0) {
           slot = page;
-        } else if (atomicAdd(cursor + PLAN_CTR_REQUESTS, 1u) < tail_chunks) {
-          slot = direct ? pool_chunks - 1u - atomicAdd(cursor + PLAN_CTR_DIRECT, 1u) : n_pages + atomicAdd(cursor + PLAN_CTR_TAIL, 1u);
-          if (direct && emitted == 0) write_empty_chunk(pool, page);  // the sliced kernel finds nothing at the page's slot
+        } else {
+          const uint32_t f = atomicAdd(cursor + PLAN_CTR_TAIL, 1u);
+          if (front_limit > n_pages && f < front_limit - n_pages) slot = n_pages + f;
         }
         st.chunk_slot = slot;
       }
@@ -937,38 +984,27 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         hd->page = page;
         hd->dict = (uint64_t)(uintptr_t)d.dict;
         hd->dict_len = d.dict_len;
-        hd->reserved[0] = 0;  // not a chunk of equal runs
-        hd->reserved[1] = 0;
+        hd->reserved[0] = regular ? V : 0u;  // != 0: a chunk of equal runs
+        hd->reserved[1] = regular ? S : 0u;
+        // A chunk that is not regular: the batch cannot take the regular path of k_dict_pages_sliced (flag in
+        // counter 3), unless there are only a few such chunks among thousands (one run of eight equal ids
+        // somewhere in a column): the first PLAN_IRREGULAR_LIST of them are listed, the regular path skips
+        // them and the left-over launch expands them with a gather from memory.  (The flag is a store and
+        // the list is short on purpose: thousands of atomics on one word queue up behind each other.)
+        if (want_dict && !direct && !regular) {
+          bool listed = false;
+          if (d.dict_len > 3u * DP_QUARTER_ENTRIES && direct_max != 0 &&
+              __hip_atomic_load(cursor + PLAN_CTR_IRREGULAR_LISTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PLAN_IRREGULAR_LIST) {
+            const uint32_t idx = atomicAdd(cursor + PLAN_CTR_IRREGULAR_LISTED, 1u);
+            if (idx < PLAN_IRREGULAR_LIST) {
+              cursor[PLAN_CTR_LIST0 + idx] = slot;
+              listed = true;
+            }
+          }
+          if (!listed) cursor[PLAN_CTR_IRREGULAR] = 1u;
+        }
       }
       __syncthreads();
-      // Chunks of dictionary pages that are nothing but whole bit-packed runs at one distance from
-      // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
-      // chunks; the others are counted, and a batch without any is gathered by the regular path of k_dict_pages_sliced.
-      if (want_dict && !direct) {
-        const uint32_t s0 = chunk[0].start4, c0 = chunk[0].src;
-        const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
-        bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
-                  d.dict_len > 3u * DP_QUARTER_ENTRIES;  // (that kernel sweeps four quarters per plane)
-        uint32_t V = 1u << 20, S = 0;  // a single run: every unit lies in run 0
-        if (k >= 2) {
-          V = (chunk[1].start4 >> 2) - (s0 >> 2);
-          S = chunk[1].src - c0;
-          ok = ok && V != 0 && (V & 3u) == 0 && V <= (1u << 20);
-        }
-        bool bad = false;
-        for (uint32_t i = tid; i < k; i += PLAN_THREADS)
-          bad = bad || chunk[i].start4 != s0 + ((i * V) << 2) || chunk[i].src != c0 + i * S;
-        ok = ok && __builtin_amdgcn_ballot_w64(bad) == 0;
-        if (tid == 0) {
-          RleChunkHead* hd = reinterpret_cast<RleChunkHead*>(chunk + SEG_HEAD_SLOT);
-          if (ok) {
-            hd->reserved[0] = V;
-            hd->reserved[1] = S;
-          } else {
-            atomicAdd(cursor + PLAN_CTR_IRREGULAR, 1u);
-          }
-        }
-      }
       uint8_t* table = reinterpret_cast<uint8_t*>(chunk + SEG_TABLE_SLOT);
       for (uint32_t b = tid; b < (uint32_t)SEG_TABLE_BLOCKS; b += PLAN_THREADS) {
         const uint32_t first = v0 + b * SEG_BLOCK;

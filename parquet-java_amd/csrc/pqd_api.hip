@@ -23,7 +23,7 @@ constexpr uint32_t NOALLOC_MAX_PAGES = 2048;
 constexpr uint32_t NOALLOC_POOL_CHUNKS = 8192;  // chunk p for page p, the rest shared
 constexpr size_t NOALLOC_POOL_BYTES = (size_t)NOALLOC_POOL_CHUNKS * pqd::SEG_CHUNK * sizeof(pqd::RleSeg);
 constexpr size_t NOALLOC_PLANS_BYTES = (size_t)NOALLOC_MAX_PAGES * sizeof(pqd::RlePagePlan);
-constexpr size_t NOALLOC_COUNTER_BYTES = 256 + (size_t)pqd::DP_MAX_SLOTS * 12;  // counters, plane key table, plane slot list
+constexpr size_t NOALLOC_COUNTER_BYTES = pqd::PLAN_COUNTER_BYTES + (size_t)pqd::DP_MAX_SLOTS * 12;  // counters, plane key table, plane slot list
 constexpr uint32_t NOALLOC_PLANE_SLOTS = 8;  // plane copies of 8-byte dictionaries swept through LDS
 constexpr size_t NOALLOC_PLANE_BYTES = (size_t)NOALLOC_PLANE_SLOTS * pqd::DP_SLOT_BYTES;
 constexpr size_t NOALLOC_BYTES = NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES + NOALLOC_COUNTER_BYTES + NOALLOC_PLANE_BYTES;
@@ -113,7 +113,7 @@ struct PlanScratch {
   void* plane_area = nullptr;    // plane copies of 8-byte dictionaries, plane_slots x DP_SLOT_BYTES
   uint32_t plane_slots = 0;
 };
-constexpr size_t COUNTER_BYTES = 256;
+constexpr size_t COUNTER_BYTES = pqd::PLAN_COUNTER_BYTES;
 constexpr size_t PLANE_KEYS_BYTES = (size_t)pqd::DP_MAX_SLOTS * 8, PLANE_LIST_BYTES = (size_t)pqd::DP_MAX_SLOTS * 4;
 constexpr size_t COUNTER_BLOCK_BYTES = COUNTER_BYTES + PLANE_KEYS_BYTES + PLANE_LIST_BYTES;
 
@@ -133,7 +133,7 @@ struct PlanLease {
   std::unique_lock<std::mutex> lock;
 };
 
-// Plans for n_pages pages and a chunk pool of two chunks per page plus a shared reserve (a
+// Plans for n_pages pages and a chunk pool of three chunks per page plus a shared reserve (a
 // 20000-value level page needs 1-6 chunks, a 1 M-value page about 31; a page that finds the pool
 // empty is decoded by the generic kernel).  Returns with the scratch locked.
 int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_plane_slots, PlanLease* lease) {
@@ -145,7 +145,7 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_pla
     ps = &g_plan_scratch[std::make_pair(dev, (void*)stream)];
   }
   std::unique_lock<std::mutex> lock(ps->mu);
-  const uint64_t want = (uint64_t)n_pages * 2 + 16384;
+  const uint64_t want = (uint64_t)n_pages * 3 + 32768;  // (dictionary pages split the tail behind the page slots into two halves)
   if (want_plane_slots > pqd::DP_MAX_SLOTS) want_plane_slots = pqd::DP_MAX_SLOTS;
   if (ps->cap_pages < n_pages || ps->gen_chunks < want || !ps->counters || ps->plane_slots < want_plane_slots) {
     // wait for work that may still use the old buffers, then replace them
@@ -617,7 +617,10 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
                                             elem_size, planes, false, s));
         PQD_HIP(pqd::launch_dict_planes(planes, ps.counters, s));
         if ((st = phase_mark(1, s))) return st;
-        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pool_chunks, ps.counters, n_pages, elem_size, planes.area, s));
+        // (the sliced gather takes the page slots and the front half of the pool's tail; the back half holds the
+        // chunks that the left-over launch expands)
+        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pqd::plan_front_limit(pool_chunks, n_pages, true), ps.counters, n_pages,
+                                              elem_size, planes.area, s));
         if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s, ps.gen_pool, pool_chunks, ps.counters));
         if ((st = phase_mark(3, s))) return st;
@@ -700,7 +703,8 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
                                       use_small_rle_kernel(), s));
   if (dict) {
     PQD_HIP(pqd::launch_dict_planes(planes, counters, s));
-    PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pool_chunks, counters, n_pages, elem_size, planes.area, s));
+    PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pqd::plan_front_limit(pool_chunks, n_pages, true), counters, n_pages, elem_size,
+                                          planes.area, s));
   } else
     PQD_HIP(pqd::launch_rle_expand(pool, pool_chunks, counters, n_pages, s));
   PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s, dict ? pool : nullptr, pool_chunks, counters));

@@ -298,18 +298,24 @@ __device__ __forceinline__ void expand_tile(const PQD_LDS RleSeg* cs, const ExHe
 // EX_UNITS words; slow_n: 2 words (all in LDS).
 template <int ELEM>
 __device__ __forceinline__ void dict_expand_direct_chunks(pqd_page_result* __restrict__ results, const RleSeg* __restrict__ pool,
-                                                          uint32_t pool_chunks, const uint32_t* __restrict__ cursor, RleSeg* cs_buf,
-                                                          uint32_t* slow_list, uint32_t* slow_n) {
+                                                          uint32_t pool_chunks, uint32_t n_pages, const uint32_t* __restrict__ cursor,
+                                                          RleSeg* cs_buf, uint32_t* slow_list, uint32_t* slow_n) {
   const uint32_t n_direct = ex_uni(cursor[PLAN_CTR_DIRECT]);
-  if (n_direct == 0u) return;
+  // the few irregular chunks of a batch that took the regular path of the sliced gather (listed by the plan kernel)
+  uint32_t n_listed = ex_uni(cursor[PLAN_CTR_IRREGULAR]) == 0u ? ex_uni(cursor[PLAN_CTR_IRREGULAR_LISTED]) : 0u;
+  if (n_listed > PLAN_IRREGULAR_LIST) n_listed = PLAN_IRREGULAR_LIST;
+  if (n_direct + n_listed == 0u) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t wave = ex_uni(tid >> 6);
   const PQD_LDS RleSeg* cs = (const PQD_LDS RleSeg*)cs_buf;
   uint32_t parity = 0;
   __syncthreads();  // whatever used this LDS before is done
   if (tid < 2) slow_n[tid] = 0;
-  for (uint32_t i = blockIdx.x; i < n_direct && i < pool_chunks; i += gridDim.x) {
-    const uint32_t c = pool_chunks - 1u - i;
+  const uint32_t back_cap = pool_chunks - plan_front_limit(pool_chunks, n_pages, true);  // chunks the plan kernel could grant at the end
+  const uint32_t n_mine = n_direct < back_cap ? n_direct : back_cap;
+  for (uint32_t i = blockIdx.x; i < n_mine + n_listed; i += gridDim.x) {
+    const uint32_t c = i < n_mine ? pool_chunks - 1u - i : ex_uni(cursor[PLAN_CTR_LIST0 + (i - n_mine)]);
+    if (c >= pool_chunks) continue;
     __syncthreads();  // everybody is done with the previous chunk
     {
       const PQD_GLOBAL uint64_t* src = (const PQD_GLOBAL uint64_t*)(pool + (size_t)c * SEG_CHUNK);

@@ -7,6 +7,7 @@
 // kernels that move the bulk of the bytes then start from the table and contain no serial code.
 #pragma once
 
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace pqd {
@@ -66,15 +67,29 @@ static_assert(sizeof(RleChunkHead) == 64, "chunk header is 64 bytes");
 // first chunk, the page's own slot holds an empty chunk.
 constexpr uint32_t DS_DIRECT_MAX = 8192;
 
+// The pool of a call that plans dictionary pages: n_pages page slots, then the shared tail, of which the front half
+// serves the chunks of the sliced gather (counter 0, growing upwards from slot n_pages) and the back half the chunks
+// of k_dict_expand (counter 4, growing downwards from the last slot).  Plain hybrid pages use the whole tail from the
+// front.  plan_front_limit: the first slot the front may NOT use (what the consumers of the front take as the pool's size).
+__host__ __device__ inline uint32_t plan_front_limit(uint32_t pool_chunks, uint32_t n_pages, bool want_dict) {
+  if (pool_chunks <= n_pages || !want_dict) return pool_chunks;
+  return pool_chunks - (pool_chunks - n_pages) / 2u;
+}
+
 // The call's counter block (32-bit counters, zeroed per call):
-//   0  chunks taken from the front of the pool's shared tail (behind the n_pages page slots)
+//   0  chunks asked for at the front of the pool's shared tail (behind the n_pages page slots; granted below plan_front_limit)
 //   1  pages left to the generic kernel (their list: RlePagePlan::fallback_page)
 //   2  plane slots claimed in this call (DictPlanes::list)
-//   3  dictionary chunks that are not regular (0: the batch takes the regular path of k_dict_pages_sliced)
-//   4  chunks taken from the end of the pool (k_dict_expand's)
-//   5  requests for chunks of the shared tail, granted or not (front and end together never exceed it)
+//   3  non-zero: dictionary chunks that are neither regular nor listed exist (0: the batch takes the regular path
+//      of k_dict_pages_sliced)
+//   4  chunks asked for at the end of the pool (k_dict_expand's; granted down to plan_front_limit)
+//   6  irregular chunks of large dictionaries that were listed (while counter 3 is zero they are all listed: the
+//      regular path skips them, the left-over launch expands them)
+//   64 .. 64 + PLAN_IRREGULAR_LIST - 1   their pool slots
 constexpr int PLAN_CTR_TAIL = 0, PLAN_CTR_FALLBACK = 1, PLAN_CTR_PLANES = 2, PLAN_CTR_IRREGULAR = 3, PLAN_CTR_DIRECT = 4,
-              PLAN_CTR_REQUESTS = 5;
+              PLAN_CTR_IRREGULAR_LISTED = 6, PLAN_CTR_LIST0 = 64;
+constexpr uint32_t PLAN_IRREGULAR_LIST = 256;
+constexpr uint32_t PLAN_COUNTER_BYTES = (PLAN_CTR_LIST0 + PLAN_IRREGULAR_LIST) * 4;
 
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
 constexpr uint32_t PLAN_F_SMALL_DONE = 4u;  // decoded by k_rle_small_pages before the plan kernel ran (which turns it into PLAN_F_DONE)

@@ -720,7 +720,22 @@ def test_dictionary_batches_of_regular_chunks(gpu, orc, monkeypatch, elem, mode)
         assert st == ost and written == ovals.size, (i, st, written, ost, ovals.size)
         assert (out.view(dt)[:written] == ovals).all(), i
         assert (guard == 0xA5).all(), i
-    if mode == "only":  # the switch does what the test relies on: a batch with one irregular chunk is not written at all
+    # a few irregular chunks (here: pages with an RLE run) in a large batch go to the left-over kernel's gather from
+    # memory and the batch keeps the regular path: one in sixteen pages at most, 5 of these 96
+    dic = rng.integers(-(1 << 31), 1 << 31, 65536).astype(dt)
+    many, want = [], []
+    for i in range(96):
+        ids = non_repeating(6000 + 13 * i, 65536)
+        if i in (7, 40, 41, 90):
+            ids[1000:1100] = 4242
+        many.append(gpu.Page(orc.dict_encode_ids(ids, 65536), ids.size, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        want.append(dic[ids])
+    monkeypatch.setenv("PQD_DIRECT_MAX", "4096")  # (the pages themselves are longer than that: only the budget sends chunks away)
+    for i, ((st, written, _, out, guard), w_) in enumerate(zip(gpu.decode_pages(many), want)):
+        assert st == 0 and written == w_.size and (out.view(dt) == w_).all() and (guard == 0xA5).all(), i
+    monkeypatch.delenv("PQD_DIRECT_MAX")
+    if mode == "only":  # the switch does what the test relies on: a batch with an irregular chunk that is not listed is not written at all
+        monkeypatch.setenv("PQD_DIRECT_MAX", "0")  # (no chunk is handed to the left-over launch)
         dic = rng.integers(-(1 << 31), 1 << 31, 65536).astype(dt)
         ids = non_repeating(20000, 65536)
         ids[5000:5100] = 77  # an RLE run

@@ -22,6 +22,10 @@ def main():
             os.environ["PQD_DICT_PATH"] = path
             ms = timeit(call)
             print(f"elem={elem} path={path}: {ms*1e3:8.1f} us", flush=True)
+        if os.environ.get("DBG_SPOIL"):  # the profiled call finds nothing of its input in the caches
+            spoiler = torch.zeros(64 << 20, dtype=torch.int64, device=dev)
+            spoiler.sum()
+            spoiler.sum()
         os.environ["PQD_PROF_PRINT"] = "1"
         call()
         torch.cuda.synchronize()
