@@ -686,6 +686,9 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   }
   __syncthreads();
 
+  // dictionaries the regular path of k_dict_pages_sliced takes: resident in LDS, or swept in four quarters per plane
+  // (4-byte dictionaries only for the resident kind: see gather_regular_batch)
+  const bool regular_dictionary = want_dict && (d.dict_len > 3u * DP_QUARTER_ENTRIES || (elem == 4 && d.dict_len <= 2u * DP_QUARTER_ENTRIES));
   const uint32_t front_limit = plan_front_limit(pool_chunks, n_pages, want_dict != 0);  // slots below it: page slots + front of the tail
   const uint32_t seg_groups_cap = w ? (uint32_t)PLAN_SEG_MAX_BYTES / w : 1u;
   uint32_t v0 = 0;  // start of the chunk being collected
@@ -804,7 +807,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
               hd.reserved[1] = S;
               *reinterpret_cast<RleChunkHead*>(out + SEG_HEAD_SLOT) = hd;
               // (the regular path of k_dict_pages_sliced takes batches of such chunks over four-quarter dictionaries only)
-              if (c == 0 && d.dict_len <= 3u * DP_QUARTER_ENTRIES) cursor[PLAN_CTR_IRREGULAR] = 1u  /* a flag, not a count: thousands of atomics on one word queue up behind each other */;
+              if (c == 0 && regular_dictionary) cursor[d.dict_len > 3u * DP_QUARTER_ENTRIES ? PLAN_CTR_SWEPT : PLAN_CTR_RESIDENT] = 1u;
+              if (c == 0 && !regular_dictionary) cursor[PLAN_CTR_IRREGULAR] = 1u  /* a flag, not a count: thousands of atomics on one word queue up behind each other */;
             }
             if (tid < (uint32_t)SEG_TABLE_BLOCKS / 4) {  // segment of every 256th value, four entries per lane
               uint32_t packed = 0;
@@ -931,7 +935,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         const uint32_t s0 = stage[0].start4, c0 = stage[0].src;
         const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
         bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
-                  d.dict_len > 3u * DP_QUARTER_ENTRIES;  // (that path sweeps four quarters per plane)
+                  regular_dictionary;  // (that path keeps a dictionary resident or sweeps four quarters per plane)
         if (k >= 2) {
           V = (stage[1].start4 >> 2) - (s0 >> 2);
           S = stage[1].src - c0;
@@ -986,6 +990,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         hd->dict_len = d.dict_len;
         hd->reserved[0] = regular ? V : 0u;  // != 0: a chunk of equal runs
         hd->reserved[1] = regular ? S : 0u;
+        if (regular) cursor[d.dict_len > 3u * DP_QUARTER_ENTRIES ? PLAN_CTR_SWEPT : PLAN_CTR_RESIDENT] = 1u;
         // A chunk that is not regular: the batch cannot take the regular path of k_dict_pages_sliced (flag in
         // counter 3), unless there are only a few such chunks among thousands (one run of eight equal ids
         // somewhere in a column): the first PLAN_IRREGULAR_LIST of them are listed, the regular path skips
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         // the list is short on purpose: thousands of atomics on one word queue up behind each other.)
         if (want_dict && !direct && !regular) {
           bool listed = false;
-          if (d.dict_len > 3u * DP_QUARTER_ENTRIES && direct_max != 0 &&
+          if (regular_dictionary && direct_max != 0 &&
               __hip_atomic_load(cursor + PLAN_CTR_IRREGULAR_LISTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PLAN_IRREGULAR_LIST) {
             const uint32_t idx = atomicAdd(cursor + PLAN_CTR_IRREGULAR_LISTED, 1u);
             if (idx < PLAN_IRREGULAR_LIST) {

@@ -302,7 +302,9 @@ __device__ __forceinline__ void dict_expand_direct_chunks(pqd_page_result* __res
                                                           RleSeg* cs_buf, uint32_t* slow_list, uint32_t* slow_n) {
   const uint32_t n_direct = ex_uni(cursor[PLAN_CTR_DIRECT]);
   // the few irregular chunks of a batch that took the regular path of the sliced gather (listed by the plan kernel)
-  uint32_t n_listed = ex_uni(cursor[PLAN_CTR_IRREGULAR]) == 0u ? ex_uni(cursor[PLAN_CTR_IRREGULAR_LISTED]) : 0u;
+  const bool regular_mode = ex_uni(cursor[PLAN_CTR_IRREGULAR]) == 0u &&
+                            (ex_uni(cursor[PLAN_CTR_RESIDENT]) == 0u || ex_uni(cursor[PLAN_CTR_SWEPT]) == 0u);  // as k_dict_pages_sliced decides
+  uint32_t n_listed = regular_mode ? ex_uni(cursor[PLAN_CTR_IRREGULAR_LISTED]) : 0u;
   if (n_listed > PLAN_IRREGULAR_LIST) n_listed = PLAN_IRREGULAR_LIST;
   if (n_direct + n_listed == 0u) return;
   const uint32_t tid = threadIdx.x;

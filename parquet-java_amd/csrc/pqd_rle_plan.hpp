@@ -85,9 +85,12 @@ __host__ __device__ inline uint32_t plan_front_limit(uint32_t pool_chunks, uint3
 //   4  chunks asked for at the end of the pool (k_dict_expand's; granted down to plan_front_limit)
 //   6  irregular chunks of large dictionaries that were listed (while counter 3 is zero they are all listed: the
 //      regular path skips them, the left-over launch expands them)
+//   7 / 8  non-zero: some regular chunk has a dictionary that is swept through LDS / that stays resident there (the
+//      regular path takes batches of one kind)
 //   64 .. 64 + PLAN_IRREGULAR_LIST - 1   their pool slots
 constexpr int PLAN_CTR_TAIL = 0, PLAN_CTR_FALLBACK = 1, PLAN_CTR_PLANES = 2, PLAN_CTR_IRREGULAR = 3, PLAN_CTR_DIRECT = 4,
-              PLAN_CTR_IRREGULAR_LISTED = 6, PLAN_CTR_LIST0 = 64;
+              PLAN_CTR_IRREGULAR_LISTED = 6, PLAN_CTR_SWEPT = 7, PLAN_CTR_RESIDENT = 8,
+              PLAN_CTR_LIST0 = 64;
 constexpr uint32_t PLAN_IRREGULAR_LIST = 256;
 constexpr uint32_t PLAN_COUNTER_BYTES = (PLAN_CTR_LIST0 + PLAN_IRREGULAR_LIST) * 4;
 
