@@ -924,14 +924,14 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         k = hi;
       }
       // short chunks over a dictionary that is swept go to k_dict_expand: they are taken from the pool's end
-      const bool direct = want_dict && v1 - v0 <= direct_max &&
-                    (elem == 8 ? d.dict_len > DP_QUARTER_ENTRIES : (uint64_t)d.dict_len * 4u > 2ull * DS_SLICE_BYTES);
+      const bool short_chunk = want_dict && v1 - v0 <= direct_max &&
+                               (elem == 8 ? d.dict_len > DP_QUARTER_ENTRIES : (uint64_t)d.dict_len * 4u > 2ull * DS_SLICE_BYTES);
       // Chunks of dictionary pages that are nothing but whole bit-packed runs at one distance from
       // each other (the last one may be shorter) are marked regular, as the bulk path above marks its
       // chunks; a batch without any other chunk is gathered by the regular path of k_dict_pages_sliced.
       bool regular = false;
       uint32_t V = 1u << 20, S = 0;  // a single run: every unit lies in run 0
-      if (want_dict && !direct) {
+      if (want_dict) {
         const uint32_t s0 = stage[0].start4, c0 = stage[0].src;
         const uint32_t in_off = (uint32_t)(uintptr_t)d.data & 3u;
         bool ok = w >= 1 && k >= 1 && (s0 & 3u) == SEG_PACKED_BIT && ((s0 >> 2) & 3u) == 0 && in_off + d.data_len >= 12u &&
@@ -946,6 +946,9 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
           bad = bad || stage[i].start4 != s0 + ((i * V) << 2) || stage[i].src != c0 + i * S;
         regular = ok && __builtin_amdgcn_ballot_w64(bad) == 0;
       }
+      // (the short last chunk of a long regular page stays with the sliced gather: one more chunk of a sweep that
+      // is running anyway costs less than a workgroup of its own in the left-over launch)
+      const bool direct = short_chunk && (n_values <= direct_max || !regular);
       if (tid == 0) {
         // the first chunk of page p is pool chunk p (thousands of pages asking one counter for a slot
         // at the same time would queue up behind each other); further chunks come from the shared tail
