@@ -145,9 +145,10 @@ int pqd_event_elapsed_ms(void* start, void* stop, float* ms);
  * While enabled, the calling thread's calls (at most 4096 of them) record HIP events between the
  * launches on the call's stream.  pqd_phase_ms_mean waits for those calls, returns the mean
  * duration of each of the three launches in milliseconds and the number of calls averaged, and
- * starts a new series (disabling only pauses the recording).  enable = 2 records only the two events
- * around the gather launch (ms[0] and ms[2] then read 0): every event costs the stream a few
- * microseconds.  No counterpart in the reference; off by default.
+ * starts a new series (disabling only pauses the recording).  enable = 2 times the gather launch alone,
+ * with two events that the launch itself records at the kernel's start and end (ms[0] and ms[2] then
+ * read 0): an event recorded between two launches costs the stream a few microseconds.  No counterpart
+ * in the reference; off by default.
  */
 int pqd_set_phase_timing(int enable);
 int pqd_phase_ms_mean(float ms[3], int* n_calls);

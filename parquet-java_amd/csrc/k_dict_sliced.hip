@@ -29,6 +29,8 @@
 // (dictionary bytes per tile, i.e. a few bytes per value).  Small dictionaries (one slice) stay
 // resident across chunks.  Pages this kernel is not made for (ids wider than 16 bits, a dictionary
 // too large to sweep) are flagged by the plan kernel and left to the generic kernel.
+#include <hip/hip_ext.h>
+
 #include "pqd_device.hpp"
 #include <cstdlib>
 #include <cstring>
@@ -1187,7 +1189,8 @@ static void prof_report(uint32_t grid, hipStream_t stream) {
 #endif
 
 hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
-                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream) {
+                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream,
+                                    hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (n_pages == 0) return hipSuccess;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -1218,6 +1221,17 @@ hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, 
   const uint32_t regular_only = reg_env && strcmp(reg_env, "only") == 0 ? 2u : 0u;  // (tests: the general path stays idle)
   const char* stg_env = getenv("PQD_DICT_STAGGER");
   const uint32_t stagger = stg_env ? (uint32_t)atoi(stg_env) : 10u;
+#ifndef PQD_PROF
+  if (ev_start && ev_stop) {  // timed launch: the dispatch records the kernel's own start and end
+    if (elem == 4)
+      hipExtLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, ev_start, ev_stop, 0, results, sp,
+                            pool_chunks, cursor, n_pages, plane_area, regular ? 1u | regular_only | (stagger << 8) : 0u);
+    else
+      hipExtLaunchKernelGGL(k_dict_pages_sliced<8>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, ev_start, ev_stop, 0, results, sp,
+                            pool_chunks, cursor, n_pages, plane_area, regular ? 1u | regular_only | (stagger << 8) : 0u);
+    return hipGetLastError();
+  }
+#endif
   if (elem == 4)
     hipLaunchKernelGGL(k_dict_pages_sliced<4>, dim3(grid), dim3(DS_THREADS), DS_LDS_BYTES, stream, results, sp, pool_chunks, cursor, n_pages, plane_area, regular ? 1u | regular_only | (stagger << 8) : 0u PROF_ARG);
   else

@@ -286,10 +286,20 @@ int phase_mark(int i, hipStream_t s) {
       t.events.push_back(e);
     }
   }
-  if (t.gather_only && i == 0) return PQD_OK;
+  if (t.gather_only) return PQD_OK;  // (mark 0 made sure the events exist; the gather launch records 1 and 2)
   PQD_HIP(hipEventRecord(t.events[t.used * 4 + i], s));
   if (i == 3) ++t.used;
   return PQD_OK;
+}
+
+// Mode 2 of the phase timing: the two events of the current set that the gather launch itself records (start and end
+// of the kernel, attached to its dispatch: no event packets in front of or behind it).  Null when the mode is off.
+void phase_gather_events(hipEvent_t* start, hipEvent_t* stop) {
+  *start = *stop = nullptr;
+  PhaseTimer& t = g_phase;
+  if (!t.enabled || !t.gather_only || t.used >= PHASE_MAX_CALLS || t.events.size() < (t.used + 1) * 4) return;
+  *start = t.events[t.used * 4 + 1];
+  *stop = t.events[t.used * 4 + 2];
 }
 
 // Which kernels decode dictionary pages: the planned path (header-walk kernel + LDS-sliced gather,
@@ -619,8 +629,10 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if ((st = phase_mark(1, s))) return st;
         // (the sliced gather takes the page slots and the front half of the pool's tail; the back half holds the
         // chunks that the left-over launch expands)
+        hipEvent_t ev_start, ev_stop;
+        phase_gather_events(&ev_start, &ev_stop);
         PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pqd::plan_front_limit(pool_chunks, n_pages, true), ps.counters, n_pages,
-                                              elem_size, planes.area, s));
+                                              elem_size, planes.area, s, ev_start, ev_stop));
         if ((st = phase_mark(2, s))) return st;
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s, ps.gen_pool, pool_chunks, ps.counters));
         if ((st = phase_mark(3, s))) return st;

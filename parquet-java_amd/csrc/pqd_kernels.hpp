@@ -40,8 +40,10 @@ hipError_t launch_dict_planes(const DictPlanes& planes, const uint32_t* cursor, 
 hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream);
 // planned dictionary pages: expansion + sliced LDS gather
+// (ev_start / ev_stop, if given: events that the launch itself records at the kernel's start and end)
 hipError_t launch_dict_pages_sliced(pqd_page_result* results, const void* pool, uint32_t pool_chunks, const uint32_t* cursor,
-                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream);
+                                    uint32_t n_pages, int elem, const uint8_t* plane_area, hipStream_t stream,
+                                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                               hipStream_t stream);
 // DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: the length blocks into the page's work area (two result
