@@ -428,8 +428,11 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
                                                            const RlePagePlan* __restrict__ only_fallback,
                                                            const uint32_t* __restrict__ fallback_count,
                                                            const RleSeg* __restrict__ pool, uint32_t pool_chunks,
-                                                           const uint32_t* __restrict__ cursor) {
+                                                           const uint32_t* __restrict__ cursor, uint32_t* __restrict__ zero,
+                                                           uint32_t zero_words) {
   __shared__ u32x4 win4[WINDOW_PIECES];
+  // the counter block of the NEXT call on this stream (nothing in this call reads or writes it)
+  for (uint32_t i = blockIdx.x * RLE_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * RLE_THREADS) zero[i] = 0u;
   static_assert(sizeof(u32x4) * WINDOW_PIECES >= sizeof(RleSeg) * SEG_CHUNK + 4 * (2 * EX_THREADS * EX_UNITS + 2), "the window holds the expansion's LDS");
   static_assert(RLE_THREADS == EX_THREADS, "one workgroup shape for both parts");
   if (!only_fallback) {
@@ -454,7 +457,8 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
 
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
-                            hipStream_t stream, const void* pool, uint32_t pool_chunks, const uint32_t* cursor) {
+                            hipStream_t stream, const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* zero,
+                            uint32_t zero_words) {
   if (n_pages == 0) return hipSuccess;
   const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
@@ -462,11 +466,11 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
   const uint32_t cap = has_dict && sp ? 1024u : 512u;
   const dim3 grid(pl && n_pages > cap ? cap : n_pages), block(RLE_THREADS);
   if (!has_dict)
-    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
+    hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor, zero, zero_words);
   else if (elem == 4)
-    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
+    hipLaunchKernelGGL((k_rle_pages<4, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor, zero, zero_words);
   else
-    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor);
+    hipLaunchKernelGGL((k_rle_pages<8, true>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor, zero, zero_words);
   return hipGetLastError();
 }
 

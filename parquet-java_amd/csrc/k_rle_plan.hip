@@ -555,8 +555,15 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
-  const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
+  // the plane copies of the 8-byte dictionaries k_dict_slots claimed slots for (the gather kernel reads them; nothing
+  // in this kernel does): a piece per workgroup, ahead of its page, instead of a launch of its own
+  if (want_dict && elem == 8 && planes.n_slots != 0) {
+    uint32_t n = __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_PLANES]);
+    if (n > planes.n_slots) n = planes.n_slots;
+    for (uint32_t item = page; item < n * DP_PIECES; item += n_pages) dict_plane_piece(planes, item, tid, PLAN_THREADS);
+  }
+  const pqd_page_desc d = descs[page];
   if (small_ran && plans[page].flags == PLAN_F_SMALL_DONE) {  // k_rle_small_pages has decoded this page
     if (tid == 0) {
       plans[page].flags = PLAN_F_DONE;

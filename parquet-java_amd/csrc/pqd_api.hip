@@ -107,9 +107,12 @@ struct PlanScratch {
   uint32_t cap_pages = 0;
   void* gen_pool = nullptr;    // chunk pool: chunk p for page p, the rest handed out through counters[0]
   uint32_t gen_chunks = 0;
-  uint32_t* counters = nullptr;  // [0] chunks the plan kernel took from the shared tail of the pool, [1] pages left
-                                 // to the generic kernel, [2] plane slots claimed; behind the counter block:
-                                 // the key table and the list of the dictionary plane slots (pqd_rle_plan.hpp)
+  uint32_t* counters = nullptr;  // TWO counter blocks (pqd_rle_plan.hpp: counters, then the key table and the list of the
+                                 // dictionary plane slots).  A call uses block `which`, which is zero when the call
+                                 // begins, and its last launch zeroes the other one for the call after it, so no call
+                                 // begins with a memset of its own (a launch of 5 us in front of a 17 us kernel).
+  int which = 0;
+  bool clean[2] = {false, false};  // the block was zeroed after its last use
   void* plane_area = nullptr;    // plane copies of 8-byte dictionaries, plane_slots x DP_SLOT_BYTES
   uint32_t plane_slots = 0;
 };
@@ -166,7 +169,10 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_pla
       PQD_HIP(hipMalloc(&ps->gen_pool, (size_t)chunks * pqd::SEG_CHUNK * sizeof(pqd::RleSeg)));
       ps->gen_chunks = (uint32_t)(chunks > 0xFFFFFFFFull ? 0xFFFFFFFFull : chunks);
     }
-    if (!ps->counters) PQD_HIP(hipMalloc((void**)&ps->counters, COUNTER_BLOCK_BYTES));
+    if (!ps->counters) {
+      PQD_HIP(hipMalloc((void**)&ps->counters, 2 * COUNTER_BLOCK_BYTES));
+      ps->clean[0] = ps->clean[1] = false;
+    }
     if (ps->plane_slots < want_plane_slots) {
       if (ps->plane_area) (void)hipFree(ps->plane_area);
       ps->plane_area = nullptr;
@@ -179,6 +185,22 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_pla
   lease->lock = std::move(lock);
   return PQD_OK;
 }
+
+// The counter block of this call (zeroed here only if the call before did not get to do it) ...
+int counters_begin(PlanScratch& ps, hipStream_t s, uint32_t** counters, uint32_t** other) {
+  uint32_t* base = ps.counters + (size_t)ps.which * (COUNTER_BLOCK_BYTES / 4);
+  *other = ps.counters + (size_t)(ps.which ^ 1) * (COUNTER_BLOCK_BYTES / 4);
+  if (!ps.clean[ps.which]) PQD_HIP(hipMemsetAsync(base, 0, COUNTER_BYTES + PLANE_KEYS_BYTES, s));
+  ps.clean[ps.which] = false;  // in use from now on
+  *counters = base;
+  return PQD_OK;
+}
+// ... and, once the call's last launch (which zeroes the other block) is enqueued, the switch to that block.
+void counters_end(PlanScratch& ps) {
+  ps.clean[ps.which ^ 1] = true;
+  ps.which ^= 1;
+}
+constexpr uint32_t COUNTER_ZERO_WORDS = (uint32_t)((COUNTER_BYTES + PLANE_KEYS_BYTES) / 4);
 
 // Frees the scratch kept for `stream` on any device (the stream must be idle).
 void plan_scratch_drop(void* stream) {
@@ -597,11 +619,13 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if (st) return st;
         PlanScratch& ps = *lease.ps;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
-        PQD_HIP(hipMemsetAsync(ps.counters, 0, COUNTER_BYTES, s));
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, false, 4,
+        uint32_t *counters, *other;
+        if ((st = counters_begin(ps, s, &counters, &other))) return st;
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, counters, n_pages, false, 4,
                                             pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, use_small_rle_kernel(), s));
-        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, ps.counters, n_pages, s));
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, ps.counters + 1, s));
+        PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, counters, n_pages, s));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, counters + 1, s, nullptr, 0, nullptr, other, COUNTER_ZERO_WORDS));
+        counters_end(ps);
       }
       return PQD_OK;
     case PQD_ENC_RLE_DICTIONARY:
@@ -619,22 +643,24 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         int st = plan_scratch_acquire(s, n_pages, elem_size == 8 ? wanted_plane_slots(n_pages) : 0u, &lease);
         if (st) return st;
         PlanScratch& ps = *lease.ps;
-        const pqd::DictPlanes planes = planes_of(ps.counters, ps.plane_area, elem_size == 8 ? usable_plane_slots(ps.plane_slots, n_pages) : 0u);
-        PQD_HIP(hipMemsetAsync(ps.counters, 0, planes.n_slots ? COUNTER_BYTES + PLANE_KEYS_BYTES : COUNTER_BYTES, s));
+        uint32_t *counters, *other;
+        if ((st = counters_begin(ps, s, &counters, &other))) return st;
+        const pqd::DictPlanes planes = planes_of(counters, ps.plane_area, elem_size == 8 ? usable_plane_slots(ps.plane_slots, n_pages) : 0u);
         if ((st = phase_mark(0, s))) return st;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
-        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, ps.counters, n_pages, true,
+        PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, counters, n_pages, true,
                                             elem_size, planes, false, s));
-        PQD_HIP(pqd::launch_dict_planes(planes, ps.counters, s));
         if ((st = phase_mark(1, s))) return st;
         // (the sliced gather takes the page slots and the front half of the pool's tail; the back half holds the
         // chunks that the left-over launch expands)
         hipEvent_t ev_start, ev_stop;
         phase_gather_events(&ev_start, &ev_stop);
-        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pqd::plan_front_limit(pool_chunks, n_pages, true), ps.counters, n_pages,
+        PQD_HIP(pqd::launch_dict_pages_sliced(results, ps.gen_pool, pqd::plan_front_limit(pool_chunks, n_pages, true), counters, n_pages,
                                               elem_size, planes.area, s, ev_start, ev_stop));
         if ((st = phase_mark(2, s))) return st;
-        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, ps.counters + 1, s, ps.gen_pool, pool_chunks, ps.counters));
+        PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, true, ps.plans, counters + 1, s, ps.gen_pool, pool_chunks, counters, other,
+                                      COUNTER_ZERO_WORDS));
+        counters_end(ps);
         if ((st = phase_mark(3, s))) return st;
       }
       return PQD_OK;
@@ -714,7 +740,6 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
   PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, plans, pool, pool_chunks, counters, n_pages, dict, elem_size, planes,
                                       use_small_rle_kernel(), s));
   if (dict) {
-    PQD_HIP(pqd::launch_dict_planes(planes, counters, s));
     PQD_HIP(pqd::launch_dict_pages_sliced(results, pool, pqd::plan_front_limit(pool_chunks, n_pages, true), counters, n_pages, elem_size,
                                           planes.area, s));
   } else

@@ -21,7 +21,8 @@ hipError_t launch_unpack_run_i64(const uint8_t* in, uint64_t in_bytes, int64_t* 
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
                             hipStream_t stream, const void* pool = nullptr, uint32_t pool_chunks = 0,
-                            const uint32_t* cursor = nullptr);
+                            const uint32_t* cursor = nullptr, uint32_t* zero = nullptr, uint32_t zero_words = 0);
+// (zero / zero_words: words the launch sets to zero besides its work: the counter block of the call after this one)
 // header walk of hybrid pages (plain ones, or dictionary pages with want_dict) -> chunks of run
 // segments in `pool` (pqd_rle_plan.hpp): `plans` holds n_pages RlePagePlan records, `pool` pool_chunks
 // chunks, `cursor` two zeroed counters (chunks taken from the pool's shared tail; pages left to the
@@ -34,7 +35,8 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
 // for every page (PLAN_F_SMALL_DONE where it decoded the page)
 hipError_t launch_rle_small_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t n_pages,
                                   hipStream_t stream);
-// fills the plane slots the plan kernel claimed (their number: cursor[2])
+// fills the plane slots k_dict_slots claimed (their number: cursor[2]); the plan kernel's launch does the same for
+// the calls that go through it (the piece routine is shared: dict_plane_piece in pqd_rle_plan.hpp)
 hipError_t launch_dict_planes(const DictPlanes& planes, const uint32_t* cursor, hipStream_t stream);
 // plain hybrid pages: expansion of all chunks
 hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,

@@ -125,6 +125,39 @@ struct DictPlanes {
   uint32_t n_slots;  // 0: no plane area (every 8-byte dictionary beyond one slice is gathered from memory)
 };
 
+// One piece (DP_PIECE_ENTRIES entries) of a claimed slot's plane copy, moved by `threads` lanes of a workgroup: item =
+// (index into DictPlanes::list) * DP_PIECES + piece.  A lane moves four entries per step: two 16-byte loads, one
+// 16-byte store per plane (whole 16-byte pieces: the planes are padded to them).
+constexpr uint32_t DP_PIECE_ENTRIES = 2048;
+constexpr uint32_t DP_PIECES = 65536 / DP_PIECE_ENTRIES;  // pieces of the largest dictionary
+typedef uint32_t dp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void dict_plane_piece(const DictPlanes& planes, uint32_t item, uint32_t tid, uint32_t threads) {
+  const uint32_t slot = planes.list[item / DP_PIECES];
+  if (slot >= planes.n_slots) return;
+  const uint64_t key = planes.keys[slot];
+  const uint32_t entries = (uint32_t)(key >> 48) + 1u;
+  const uint32_t e0 = (item % DP_PIECES) * DP_PIECE_ENTRIES;
+  if (e0 >= entries) return;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>((uintptr_t)(key & 0xFFFFFFFFFFFFull));  // 16-byte aligned (plan kernel)
+  uint32_t* lo = reinterpret_cast<uint32_t*>(planes.area + (size_t)slot * DP_SLOT_BYTES);
+  uint32_t* hi = reinterpret_cast<uint32_t*>(planes.area + (size_t)slot * DP_SLOT_BYTES + DP_PLANE_BYTES);
+  for (uint32_t e = e0 + 4u * tid; e < e0 + DP_PIECE_ENTRIES && e < entries; e += 4u * threads) {
+    dp_u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+    if (e + 4u <= entries) {
+      a = *reinterpret_cast<const dp_u32x4*>(src + 2 * (size_t)e);
+      b = *reinterpret_cast<const dp_u32x4*>(src + 2 * (size_t)e + 4);
+    } else {  // the dictionary's last one to three entries
+      uint32_t t[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      for (uint32_t j = 0; j < 2u * (entries - e); ++j) t[j] = src[2 * (size_t)e + j];
+      a = dp_u32x4{t[0], t[1], t[2], t[3]};
+      b = dp_u32x4{t[4], t[5], t[6], t[7]};
+    }
+    const dp_u32x4 l = {a.x, a.z, b.x, b.z}, h = {a.y, a.w, b.y, b.w};
+    *reinterpret_cast<dp_u32x4*>(lo + e) = l;
+    *reinterpret_cast<dp_u32x4*>(hi + e) = h;
+  }
+}
+
 // Per-page record of the plan kernel.  `flags` belongs to the page with that index; `fallback_page`
 // is a dense list: entry i names the i-th page left to the generic kernel (their number is counter 1
 // of the call's counter block).
