@@ -20,6 +20,7 @@
 #include "pqd_kernels.hpp"
 #include "pqd_expand.hpp"
 #include "pqd_rle_plan.hpp"
+#include "pqd_whole_page.hpp"
 
 namespace pqd {
 
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
                                                            const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                            const uint32_t* __restrict__ cursor, uint32_t* __restrict__ zero,
                                                            uint32_t zero_words) {
-  __shared__ u32x4 win4[WINDOW_PIECES];
+  constexpr int LDS_PIECES = HAS_DICT && (sizeof(WholePageLds) + 15) / 16 > WINDOW_PIECES ? (int)((sizeof(WholePageLds) + 15) / 16) : WINDOW_PIECES;
+  __shared__ u32x4 win4[LDS_PIECES];  // the page decoder's window; the other parts of this kernel use it when no page is being decoded
   // the counter block of the NEXT call on this stream (nothing in this call reads or writes it)
   for (uint32_t i = blockIdx.x * RLE_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * RLE_THREADS) zero[i] = 0u;
   static_assert(sizeof(u32x4) * WINDOW_PIECES >= sizeof(RleSeg) * SEG_CHUNK + 4 * (2 * EX_THREADS * EX_UNITS + 2), "the window holds the expansion's LDS");
@@ -447,6 +449,21 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
     __syncthreads();  // the next page reuses the LDS
   }
   if constexpr (HAS_DICT) {
+    // run-heavy pages the plan kernel left whole (PLAN_F_WHOLE): ids and lookups in one pass; what that routine does
+    // not cover is decoded by the page decoder above
+    if (pool && __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_WHOLE]) != 0u) {
+      static_assert(RLE_THREADS == WP_THREADS, "one workgroup shape for both parts");
+      for (uint32_t page = blockIdx.x; page < n_pages; page += gridDim.x) {
+        if (__builtin_amdgcn_readfirstlane(only_fallback[page].flags) != PLAN_F_WHOLE) continue;
+        __syncthreads();  // the previous page's LDS is done with
+        const pqd_page_desc d = descs[page];
+        if (!dict_whole_page<ELEM>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) {
+          __syncthreads();
+          rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
+        }
+      }
+      __syncthreads();
+    }
     if (pool) {
       RleSeg* cs_buf = reinterpret_cast<RleSeg*>(win4);
       uint32_t* slow_list = reinterpret_cast<uint32_t*>(cs_buf + SEG_CHUNK);

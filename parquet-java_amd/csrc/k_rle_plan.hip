@@ -18,6 +18,7 @@
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 #include "pqd_rle_plan.hpp"
+#include "pqd_whole_page.hpp"
 
 namespace pqd {
 
@@ -543,7 +544,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                                                                   RlePagePlan* __restrict__ plans, RleSeg* __restrict__ pool,
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
                                                                   uint32_t n_pages, int want_dict, int elem,
-                                                                  DictPlanes planes, int small_ran, uint32_t direct_max) {
+                                                                  DictPlanes planes, int small_ran, uint32_t direct_max,
+                                                                  uint32_t whole_max) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
@@ -634,6 +636,16 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
       r.reserved = 0;
       results[page] = r;
       plans[page].flags = PLAN_F_DONE;
+      if (page < pool_chunks) write_empty_chunk(pool, page);
+    }
+    return;
+  }
+  // Run-heavy dictionary pages (a short stream for their number of values) are not planned at all: the left-over launch
+  // decodes them whole, ids and lookups in one pass (pqd_whole_page.hpp), and falls back to its page decoder by itself.
+  if (want_dict && d.dict != nullptr && whole_page_candidate(end - pos, n_values, w, d.dict_len, whole_max)) {
+    if (tid == 0) {
+      plans[page].flags = PLAN_F_WHOLE;
+      cursor[PLAN_CTR_WHOLE] = 1u;
       if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
@@ -1089,13 +1101,17 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
   // PQD_DIRECT_MAX: chunks of dictionary pages of at most that many values are gathered from memory (0: none)
   const char* dm = getenv("PQD_DIRECT_MAX");
   const uint32_t direct_max = dm ? (uint32_t)atoi(dm) : DS_DIRECT_MAX;
+  // PQD_WHOLE_MAX: dictionary pages with a stream of at most that many bytes, at most half of what their values would
+  // take bit-packed, are decoded whole by the left-over launch (0: none)
+  const char* wm = getenv("PQD_WHOLE_MAX");
+  const uint32_t whole_max = wm ? (uint32_t)atoi(wm) : WP_MAX_BYTES;
   if (small) {  // small pages first: what it decodes the plan kernel skips
     hipError_t e = launch_rle_small_pages(descs, results, plans, n_pages, stream);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
                      reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
-                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0, direct_max);
+                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0, direct_max, whole_max);
   return hipGetLastError();
 }
 

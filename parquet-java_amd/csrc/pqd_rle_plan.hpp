@@ -83,12 +83,13 @@ __host__ __device__ inline uint32_t plan_front_limit(uint32_t pool_chunks, uint3
 //   3  non-zero: dictionary chunks that are neither regular nor listed exist (0: the batch takes the regular path
 //      of k_dict_pages_sliced)
 //   4  chunks asked for at the end of the pool (k_dict_expand's; granted down to plan_front_limit)
+//   5  non-zero: some dictionary page is marked PLAN_F_WHOLE (the left-over launch looks for them)
 //   6  irregular chunks of large dictionaries that were listed (while counter 3 is zero they are all listed: the
 //      regular path skips them, the left-over launch expands them)
 //   7 / 8  non-zero: some regular chunk has a dictionary that is swept through LDS / that stays resident there (the
 //      regular path takes batches of one kind)
 //   64 .. 64 + PLAN_IRREGULAR_LIST - 1   their pool slots
-constexpr int PLAN_CTR_TAIL = 0, PLAN_CTR_FALLBACK = 1, PLAN_CTR_PLANES = 2, PLAN_CTR_IRREGULAR = 3, PLAN_CTR_DIRECT = 4,
+constexpr int PLAN_CTR_TAIL = 0, PLAN_CTR_FALLBACK = 1, PLAN_CTR_PLANES = 2, PLAN_CTR_IRREGULAR = 3, PLAN_CTR_DIRECT = 4, PLAN_CTR_WHOLE = 5,
               PLAN_CTR_IRREGULAR_LISTED = 6, PLAN_CTR_SWEPT = 7, PLAN_CTR_RESIDENT = 8,
               PLAN_CTR_LIST0 = 64;
 constexpr uint32_t PLAN_IRREGULAR_LIST = 256;
@@ -96,6 +97,7 @@ constexpr uint32_t PLAN_COUNTER_BYTES = (PLAN_CTR_LIST0 + PLAN_IRREGULAR_LIST) *
 
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
 constexpr uint32_t PLAN_F_SMALL_DONE = 4u;  // decoded by k_rle_small_pages before the plan kernel ran (which turns it into PLAN_F_DONE)
+constexpr uint32_t PLAN_F_WHOLE = 8u;     // a run-heavy dictionary page left unplanned: decoded whole by the left-over launch (pqd_whole_page.hpp)
 constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel
 
 // Sliced dictionary gather: LDS slice size and the values one workgroup holds in registers per

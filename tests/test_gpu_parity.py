@@ -758,6 +758,7 @@ def test_dictionary_short_chunks_gathered_from_memory(gpu, orc, monkeypatch, ele
     import parquet_java_amd as pq
     monkeypatch.setenv("PQD_DICT_PATH", "sliced")
     monkeypatch.setenv("PQD_DIRECT_MAX", direct_max)
+    monkeypatch.setenv("PQD_WHOLE_MAX", "0")  # (run-heavy pages would otherwise be decoded whole and never be cut into chunks)
     if pool is not None:
         monkeypatch.setenv("PQD_POOL_CHUNKS", pool)
     dt = np.int32 if elem == 4 else np.int64
@@ -791,3 +792,69 @@ def test_dictionary_short_chunks_gathered_from_memory(gpu, orc, monkeypatch, ele
         assert st == ost and written == ovals.size, (i, st, written, ost, ovals.size)
         assert (out.view(dt)[:written] == ovals).all(), i
         assert (guard == 0xA5).all(), i
+
+
+@pytest.mark.parametrize("elem", [4, 8])
+def test_dictionary_run_heavy_pages_decoded_whole(gpu, orc, monkeypatch, elem):
+    """Dictionary pages whose stream is short for their number of values (at most 8 KiB and at most half of the
+    bit-packed size: sorted or clustered ids) are not planned: the left-over launch parses the whole stream in LDS
+    and looks the ids up in one pass.  Widths from 1 to 21 bits, one run of 20000 values behind a three-byte
+    header, the largest page the path takes and the first it does not, ids beyond the dictionary in an RLE run and
+    in a bit-packed group, an RLE value wider than the page's bit width (the reference does not mask it), and
+    streams the path must hand to the page decoder (a zero-length run, a cut-off run, a stream that ends short of
+    the page).  PQD_WHOLE_MAX=0 switches the path off: statuses, counts, consumed bytes and values must agree with
+    that run and with the oracle."""
+    import parquet_java_amd as pq
+    dt = np.int32 if elem == 4 else np.int64
+    rng = np.random.default_rng(6300 + elem)
+    pages, expect = [], []
+
+    def dictionary(n):
+        d = rng.integers(-(1 << 31), 1 << 31, n).astype(dt)
+        return d * np.int64(0x100000001) + 3 if elem == 8 else d
+
+    def add(data, n, d):
+        data = np.asarray(data, np.uint8)
+        pages.append(gpu.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=d))
+        expect.append(orc.dict_decode(data, d, n))
+
+    def runs(n, reach, n_runs, longest):
+        x = np.sort(rng.integers(0, reach, n_runs)).repeat(rng.integers(1, longest, n_runs))[:n].astype(np.int32)
+        return np.concatenate([x, np.full(n - x.size, x[-1], np.int32)])
+
+    for n_dict in (2, 30, 4096, 65536, (1 << 20) + 1):
+        d = dictionary(n_dict)
+        for n in (20000, 32768, 32769, 1000, 7):
+            ids = runs(n, n_dict, max(n // 33, 1), 70)
+            add(orc.dict_encode_ids(ids, n_dict), n, d)
+        add(orc.dict_encode_ids(np.full(20000, n_dict - 1, np.int32), n_dict), 20000, d)  # one run, three header bytes
+        add(orc.dict_encode_ids(rng.permutation(runs(20000, n_dict, 300, 140)), n_dict), 20000, d)  # not run-heavy at all
+    d = dictionary(40000)
+    ids = runs(20000, 40000, 600, 70)
+    ids[15000:15020] = 50000  # beyond the dictionary: an RLE run
+    add(orc.dict_encode_ids(ids, 40000), 20000, d)
+    ids = runs(20000, 40000, 600, 70)
+    ids[12000:12003] = (1, 65535, 2)  # inside a bit-packed group
+    add(orc.dict_encode_ids(ids, 40000), 20000, d)
+    # written with 12-bit ids; an RLE run whose two value bytes say 0x9C40 = 40000 (beyond) and 0x1234 (inside, above 2^12)
+    body = orc.rle_encode(12, runs(8000, 4096, 200, 80))
+    for value, n in ((0x9C40, 8600), (0x1234, 8600)):
+        add(np.concatenate([np.array([12], np.uint8), body, np.array([600 << 1 & 0x7F | 0x80, 600 >> 6, value & 0xFF, value >> 8], np.uint8)]), n, d)
+    good = orc.dict_encode_ids(runs(20000, 40000, 600, 70), 40000)
+    add(good[:-1], 20000, d)  # the last run is cut off
+    add(good[: good.size // 2], 20000, d)  # the stream ends short of the page
+    add(np.concatenate([good[:1], np.array([0, 7, 0], np.uint8), good[1:]]), 20000, d)  # a run of zero values in front
+    add(good, 20000, d)
+    results = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("PQD_WHOLE_MAX")
+        else:
+            monkeypatch.setenv("PQD_WHOLE_MAX", mode)
+        results[mode] = gpu.decode_pages(pages)
+        for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(results[mode], expect)):
+            assert st == ost and written == ovals.size, (mode, i, st, written, ost, ovals.size)
+            assert (out.view(dt)[:written] == ovals).all(), (mode, i)
+            assert (guard == 0xA5).all(), (mode, i)
+    for i, (a, b) in enumerate(zip(results["0"], results[None])):
+        assert a[2] == b[2], (i, a[2], b[2])  # bytes consumed
