@@ -5,7 +5,7 @@
 // at most 32768 values, bit widths 1..8.  That is every level page of a 20000-value data page, whose
 // streams are made of very short runs (an RLE run wherever eight equal levels meet, a few bit-packed
 // groups in between: a header every 10 to 20 values), so finding the headers is the work.
-// One workgroup of 128 threads per page:
+// One workgroup of 256 threads per page:
 //   1. the stream is copied to LDS;
 //   2. every thread reads each of the 64 bytes of its block as if a run header started there and notes
 //      where that run would end; back to front it turns these into "a chain that enters my block here
@@ -27,9 +27,11 @@
 
 namespace pqd {
 
-constexpr int RS_THREADS = 128;
-constexpr uint32_t RS_BLOCK = 64;                         // stream bytes per thread
-constexpr uint32_t RS_MAX_BYTES = RS_THREADS * RS_BLOCK;  // 8 KiB
+constexpr int RS_THREADS = 256;
+constexpr uint32_t RS_BLOCK = 64;  // stream bytes per block (a lane per byte in step 2, a thread per block in step 4)
+constexpr uint32_t RS_MAX_BYTES = 8192;
+constexpr uint32_t RS_BLOCKS = RS_MAX_BYTES / RS_BLOCK;
+static_assert(RS_BLOCKS <= (uint32_t)RS_THREADS, "a thread per block");
 constexpr uint32_t RS_MAX_VALUES = 32768;
 constexpr uint32_t RS_COMPLEX = 0xFFFFu, RS_END = 0xFFFEu;
 constexpr uint32_t RS_BIAS = 1u << 19;  // above first value * w (< 2^18)
@@ -54,16 +56,22 @@ __device__ __forceinline__ SmallRun small_run(uint32_t lo, uint32_t w) {
   return r;
 }
 
-// Exclusive prefix of `v` over the workgroup's 128 threads and the total.
+// Exclusive prefix of `v` over the workgroup's threads and the total.
 __device__ __forceinline__ uint32_t rs_exclusive(uint32_t v, uint32_t* wave_totals, uint32_t& total) {
   const uint32_t inc = wave_scan_inclusive(v);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   __syncthreads();
   if (lane == 63) wave_totals[wave] = inc;
   __syncthreads();
-  const uint32_t t0 = wave_totals[0], t1 = wave_totals[1];
-  total = t0 + t1;
-  return (wave ? t0 : 0u) + inc - v;
+  uint32_t before = 0;
+  total = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < RS_THREADS / 64; ++k) {
+    const uint32_t t = wave_totals[k];
+    before += k < wave ? t : 0u;
+    total += t;
+  }
+  return before + inc - v;
 }
 
 __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_desc* __restrict__ descs,
@@ -73,8 +81,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   __shared__ __attribute__((aligned(16))) uint16_t tab[RS_MAX_BYTES + 64];  // step 2/3: exits; step 4/5: the run table (as words)
   __shared__ __attribute__((aligned(16))) uint32_t flags[RS_MAX_VALUES / 32 + 2];
   __shared__ uint16_t wbase[RS_MAX_VALUES / 64 + 4];
-  __shared__ uint16_t entry_of[RS_THREADS];
-  __shared__ uint32_t wave_totals[2];
+  __shared__ uint16_t entry_of[RS_BLOCKS];
+  __shared__ uint32_t wave_totals[RS_THREADS / 64];
   __shared__ uint32_t s_ok, s_consumed;
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
@@ -117,20 +125,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
 #endif
   RS_STAMP();
 
-  // ---- 1. the stream -> LDS (zeros behind it)
-  for (uint32_t i = tid * 16u; i < N + 16u; i += RS_THREADS * 16u) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (i + 16u <= N) {
-      __builtin_memcpy(&v, src + i, 16);
-    } else if (i < N) {
-      uint32_t tmp[4] = {0u, 0u, 0u, 0u};
-      for (uint32_t k = 0; i + k < N; ++k) tmp[k >> 2] |= (uint32_t)src[i + k] << (8u * (k & 3u));
-      v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+  // ---- 1. the stream -> LDS (zeros behind it).  Whole aligned dwords are read (none lies wholly outside the page) and
+  // shifted into place: a piece of 16 stream bytes is five independent loads, whatever the page's address.
+  {
+    const uintptr_t a = (uintptr_t)src;
+    const PQD_GLOBAL uint32_t* wsrc = (const PQD_GLOBAL uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t off = (uint32_t)(a & 3u), sh = off * 8u;
+    const uint32_t full = (off + N) >> 2;  // dwords wholly inside [aligned start, end of stream)
+    const uint32_t tail = (off + N) & 3u;  // stream bytes in dword `full`
+    for (uint32_t i = tid * 4u; i * 4u < N + 16u; i += RS_THREADS * 4u) {
+      uint32_t x[5];
+#pragma unroll
+      for (uint32_t k = 0; k < 5u; ++k) {
+        x[k] = 0u;
+        if (i + k < full)
+          x[k] = wsrc[i + k];
+        else if (i + k == full && tail)
+          x[k] = wsrc[i + k] & ((1u << (8u * tail)) - 1u);
+      }
+      const u32x4 v = {funnel_shr(x[0], x[1], sh), funnel_shr(x[1], x[2], sh), funnel_shr(x[2], x[3], sh), funnel_shr(x[3], x[4], sh)};
+      *reinterpret_cast<u32x4*>(pg + i * 4u) = v;
     }
-    *reinterpret_cast<u32x4*>(pg + i) = v;
   }
-  for (uint32_t i = tid; i < RS_MAX_VALUES / 32 + 2; i += RS_THREADS) flags[i] = 0u;
-  entry_of[tid] = 0xFFFFu;
+  for (uint32_t i = tid; i < (n_values >> 5) + 2u; i += RS_THREADS) flags[i] = 0u;
+  if (tid < RS_BLOCKS) entry_of[tid] = 0xFFFFu;
   if (tid == 0) {
     s_ok = 1u;
     s_consumed = 0u;
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   RS_STAMP();
   // ---- 4. the runs of every block, numbered, with their first output value
   uint32_t my_runs = 0, my_vals = 0;
-  const uint32_t entry = entry_of[tid];
+  const uint32_t entry = tid < RS_BLOCKS ? entry_of[tid] : 0xFFFFu;
   if (entry != 0xFFFFu) {
     uint32_t p = entry;
     while (p < block_end && p < N) {
@@ -236,19 +254,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   RS_STAMP();
   // run starts before each 64-bit word of the bitmap
   {
-    const uint32_t words = (n_values + 63u) >> 6;  // <= 512: four per thread
-    uint32_t c[4], sum = 0;
+    const uint32_t words = (n_values + 63u) >> 6;  // <= 512: two per thread
+    uint32_t c[2], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t wd = tid * 4u + k;
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t wd = tid * 2u + k;
       c[k] = wd < words ? (uint32_t)(__builtin_popcount(flags[2 * wd]) + __builtin_popcount(flags[2 * wd + 1])) : 0u;
       sum += c[k];
     }
     uint32_t total;
     uint32_t before = rs_exclusive(sum, wave_totals, total);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      wbase[tid * 4u + k] = (uint16_t)before;
+    for (int k = 0; k < 2; ++k) {
+      wbase[tid * 2u + k] = (uint16_t)before;
       before += c[k];
     }
   }
