@@ -32,6 +32,9 @@ constexpr uint32_t RS_BLOCK = 64;  // stream bytes per block (a lane per byte in
 constexpr uint32_t RS_MAX_BYTES = 8192;
 constexpr uint32_t RS_BLOCKS = RS_MAX_BYTES / RS_BLOCK;
 static_assert(RS_BLOCKS <= (uint32_t)RS_THREADS, "a thread per block");
+constexpr uint32_t RS_GROUP = 8 * RS_BLOCK;  // step 3: blocks are hopped over in groups of eight
+constexpr uint32_t RS_GROUPS = RS_MAX_BYTES / RS_GROUP;
+static_assert(RS_GROUPS * RS_BLOCK == 4u * RS_THREADS, "four group chains per thread");
 constexpr uint32_t RS_MAX_VALUES = 32768;
 constexpr uint32_t RS_COMPLEX = 0xFFFFu, RS_END = 0xFFFEu;
 constexpr uint32_t RS_BIAS = 1u << 19;  // above first value * w (< 2^18)
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
       *reinterpret_cast<u32x4*>(pg + i * 4u) = v;
     }
   }
-  for (uint32_t i = tid; i < (n_values >> 5) + 2u; i += RS_THREADS) flags[i] = 0u;
   if (tid < RS_BLOCKS) entry_of[tid] = 0xFFFFu;
+  if (tid < RS_GROUPS) wbase[tid] = 0xFFFFu;  // (step 3's group entries; the word bases come later)
   if (tid == 0) {
     s_ok = 1u;
     s_consumed = 0u;
@@ -196,12 +199,41 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   RS_STAMP();
   __syncthreads();
   RS_STAMP();
-  // ---- 3. the chain, block by block
+  // ---- 3. the chain.  One thread hopping from block to block is a chain of dependent LDS reads as long as the stream
+  // has blocks, so: (a) for every group of eight blocks and every position of its first block, where a chain that
+  // enters there leaves the group (four such chains per thread, eight hops at most, all threads at once); (b) one
+  // thread hops from group to group (block by block only where a long run lands past a group's first block); (c) a
+  // thread per group notes where the chain enters each of its blocks.
+  uint16_t* gexit = reinterpret_cast<uint16_t*>(flags);  // RS_GROUPS x 64 exits; the bitmap is zeroed after this step
+  uint16_t* gentry = wbase;
+  static_assert(sizeof(flags) >= RS_GROUPS * RS_BLOCK * sizeof(uint16_t), "the group exits fit where the bitmap will be");
+  {
+    uint32_t p[4], lim[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; ++c) {
+      const uint32_t idx = tid + c * RS_THREADS, g = idx / RS_BLOCK;
+      p[c] = g * RS_GROUP + (idx % RS_BLOCK);
+      lim[c] = (g + 1u) * RS_GROUP < N ? (g + 1u) * RS_GROUP : N;
+    }
+#pragma unroll
+    for (int hop = 0; hop < 8; ++hop)
+#pragma unroll
+      for (uint32_t c = 0; c < 4u; ++c)
+        if (p[c] < lim[c]) p[c] = tab[p[c]];  // (RS_COMPLEX is above every limit)
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; ++c) gexit[tid + c * RS_THREADS] = (uint16_t)p[c];
+  }
+  __syncthreads();
   if (tid == 0) {
     uint32_t p = 0;
     while (p < N) {
-      entry_of[p / RS_BLOCK] = (uint16_t)p;
-      p = tab[p];
+      if (p % RS_GROUP < RS_BLOCK) {
+        gentry[p / RS_GROUP] = (uint16_t)p;
+        p = gexit[(p / RS_GROUP) * RS_BLOCK + p % RS_BLOCK];
+      } else {
+        entry_of[p / RS_BLOCK] = (uint16_t)p;
+        p = tab[p];
+      }
     }
     if (p != N) s_ok = 0u;  // RS_COMPLEX met (a chain position beyond N cannot occur)
   }
@@ -210,6 +242,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     if (tid == 0) plans[page].flags = 0;
     return;
   }
+  if (tid < RS_GROUPS) {
+    uint32_t p = gentry[tid];
+    const uint32_t lim = (tid + 1u) * RS_GROUP < N ? (tid + 1u) * RS_GROUP : N;
+    while (p < lim) {  // (no entry: 0xFFFF)
+      entry_of[p / RS_BLOCK] = (uint16_t)p;
+      p = tab[p];
+    }
+  }
+  for (uint32_t i = tid; i < (n_values >> 5) + 2u; i += RS_THREADS) flags[i] = 0u;
+  __syncthreads();
   RS_STAMP();
   // ---- 4. the runs of every block, numbered, with their first output value
   uint32_t my_runs = 0, my_vals = 0;
