@@ -69,6 +69,41 @@ def build_column(n_pages, elem, seed, device):
     return blob, page_len, ids, dictionary, out
 
 
+def build_sorted_runs_column(n_pages, seed, device):
+    """`n_pages` dictionary-id pages of sorted, run-heavy ids (a column that is sorted or clustered on its value), as
+    RunLengthBitPackingHybridEncoder lays such ids out: 250 times an RLE run of 64..80 equal ids ([varint count << 1]
+    [id, two bytes]) followed by one bit-packed group of eight ([0x03][8 x 16 bits]) that holds the end of that run and
+    the beginning of the next.  Returns (blob, page_len, ids)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cells = 250
+    delta = torch.randint(0, 9, (n_pages, cells // 2), device=device, generator=g)
+    a = torch.empty((n_pages, cells), dtype=torch.int64, device=device)
+    a[:, 0::2] = 72 - delta
+    a[:, 1::2] = 72 + delta
+    k = torch.randint(1, 8, (n_pages, cells), device=device, generator=g)
+    run_ids = torch.sort(torch.randint(0, DICT_ENTRIES, (n_pages, cells + 1), device=device, generator=g), dim=1).values
+    this_id, next_id = run_ids[:, :-1], run_ids[:, 1:]
+    cell = torch.empty((n_pages, cells, 21), dtype=torch.uint8, device=device)
+    cell[:, :, 0] = (((a << 1) & 0x7F) | 0x80).to(torch.uint8)
+    cell[:, :, 1] = (a >> 6).to(torch.uint8)
+    cell[:, :, 2] = (this_id & 0xFF).to(torch.uint8)
+    cell[:, :, 3] = (this_id >> 8).to(torch.uint8)
+    cell[:, :, 4] = 0x03
+    j = torch.arange(8, device=device).view(1, 1, 8)
+    group = torch.where(j < k.unsqueeze(-1), this_id.unsqueeze(-1), next_id.unsqueeze(-1))
+    cell[:, :, 5::2] = (group & 0xFF).to(torch.uint8)
+    cell[:, :, 6::2] = (group >> 8).to(torch.uint8)
+    page_len = 1 + cells * 21
+    blob = torch.empty((n_pages, page_len), dtype=torch.uint8, device=device)
+    blob[:, 0] = ID_WIDTH
+    blob[:, 1:] = cell.view(n_pages, cells * 21)
+    vals = torch.stack([this_id, next_id], dim=-1).reshape(-1)
+    counts = torch.stack([a + k, 8 - k], dim=-1).reshape(-1)
+    ids = torch.repeat_interleave(vals, counts).view(n_pages, PAGE_VALUES).to(torch.int32)
+    return blob, page_len, ids
+
+
 def make_descs(blob, page_len, dictionary, out, elem, device, encoding=None, flags=0):
     n_pages = blob.shape[0]
     encoding = pq.ENC_RLE_DICTIONARY if encoding is None else encoding
@@ -425,6 +460,22 @@ def main():
             "mean_value_bytes": round(total_bytes / (args.pages * PAGE_VALUES), 2), "verified_pages": chk, "verified": ok}
         pq.lib.pqd_dict_destroy(handle)
         del b_offsets, b_bytes, t_page
+
+        # the INT64 column again with sorted, run-heavy ids (a column sorted or clustered on its value): such pages
+        # are decoded whole by the left-over launch, not through the chunk plan
+        r_blob, r_len, r_ids = build_sorted_runs_column(args.pages, 4242, device)
+        c = cols[1]
+        r_descs, r_res = make_descs(r_blob, r_len, c["dictionary"], c["out"], 8, device)
+        c["out"].zero_()
+        ms = timed(lambda: pq.decode_pages_dev(r_descs.data_ptr(), r_res.data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 8, stream))
+        st_r, wr_r, _ = pq.results_from_numpy(r_res.cpu().numpy())
+        ok = bool((st_r == 0).all() and (wr_r == PAGE_VALUES).all() and torch.equal(c["out"], c["dictionary"][r_ids.long()]))
+        alg = args.pages * r_len + args.pages * PAGE_VALUES * 8
+        extras["dictionary_int64_sorted_runs_of_ids"] = {
+            "ms": round(ms, 4), "values_per_s": round(args.pages * PAGE_VALUES / ms * 1e3, 1),
+            "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
+            "page_bytes": r_len, "runs_per_page": 500, "verified": ok}
+        del r_blob, r_ids
         if not args.no_config1:
             for c in cols:  # make room: the columns of the timed region are no longer needed
                 c["out"] = c["blob"] = c["ids"] = None

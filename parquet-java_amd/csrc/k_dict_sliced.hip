@@ -662,7 +662,8 @@ __device__ __forceinline__ void gather_regular_batch(pqd_page_result* __restrict
   const uint32_t step = 1;
 #else
   uint32_t chunk = blockIdx.x;
-  if (chunk >= n_chunks) return;
+  // (a batch without a single chunk of this kind: every page went to the left-over launch, decoded whole or gathered from memory)
+  if (chunk >= n_chunks || uni(cursor[RESIDENT ? PLAN_CTR_RESIDENT : PLAN_CTR_SWEPT]) == 0u) return;
   const uint32_t step = gridDim.x;
 #endif
 
@@ -845,10 +846,6 @@ __global__ __launch_bounds__(DS_THREADS) void k_dict_pages_sliced(pqd_page_resul
   uint8_t* lds = reinterpret_cast<uint8_t*>(lds4);
   DsShared* sh = reinterpret_cast<DsShared*>(lds + DS_OFF_STATE);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(PQD_LDS uint8_t*)lds;  // LDS byte address of the dynamic block
-  // no chunk for this kernel at all (every page went to the left-over launch: decoded whole, gathered from memory, generic)
-  if (__builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_IRREGULAR] | cursor[PLAN_CTR_SWEPT] | cursor[PLAN_CTR_RESIDENT] |
-                                     cursor[PLAN_CTR_IRREGULAR_LISTED]) == 0u)
-    return;
   // a batch made of regular chunks only (the plan kernel counted no other) takes the path written for it
   if ((regular_allowed & 1u) && __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_IRREGULAR]) == 0u &&
       (__builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_RESIDENT]) == 0u || __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_SWEPT]) == 0u)) {
