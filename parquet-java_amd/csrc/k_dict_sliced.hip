@@ -654,6 +654,10 @@ __device__ __forceinline__ void gather_regular_batch(pqd_page_result* __restrict
   // read and write one window of the batch that moves along (PQD_REGULAR_SHARES: contiguous shares instead)
   uint32_t n_chunks = n_pages + uni(cursor[0]);
   if (n_chunks > pool_chunks) n_chunks = pool_chunks;
+  // a batch without a single chunk of this kind (every page went to the left-over launch, decoded whole or gathered from
+  // memory): nothing to visit.  (As a select on the count: a branch here measured 1.3 % on every other batch, through
+  // nothing but a different register allocation.)
+  if (uni(cursor[RESIDENT ? PLAN_CTR_RESIDENT : PLAN_CTR_SWEPT]) == 0u) n_chunks = 0u;
   const uint32_t share = (n_chunks + gridDim.x - 1) / gridDim.x;
 #ifdef PQD_REGULAR_SHARES
   uint32_t chunk = blockIdx.x * share;
@@ -662,8 +666,7 @@ __device__ __forceinline__ void gather_regular_batch(pqd_page_result* __restrict
   const uint32_t step = 1;
 #else
   uint32_t chunk = blockIdx.x;
-  // (a batch without a single chunk of this kind: every page went to the left-over launch, decoded whole or gathered from memory)
-  if (chunk >= n_chunks || uni(cursor[RESIDENT ? PLAN_CTR_RESIDENT : PLAN_CTR_SWEPT]) == 0u) return;
+  if (chunk >= n_chunks) return;
   const uint32_t step = gridDim.x;
 #endif
 
