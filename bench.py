@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the 32-width sweep of 1 M-value hybrid pages in extras")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="the timed workload only (profiler passes: every launch of a kernel in the trace then belongs to it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -366,7 +368,7 @@ def main():
 
     # ---- outside the timed region: the other shapes of this workload, for the record
     extras = {}
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         spoiler = torch.zeros(64 << 20, dtype=torch.int64, device=device)
         def timed(fn, iters=10):  # noqa: E306
             """Mean time of fn() by events around every call, with a read of 512 MiB of unrelated data between the
