@@ -454,9 +454,9 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
     if (pool && __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_WHOLE]) != 0u) {
       static_assert(RLE_THREADS == WP_THREADS, "one workgroup shape for both parts");
       for (uint32_t page = blockIdx.x; page < n_pages; page += gridDim.x) {
+        const pqd_page_desc d = descs[page];  // (requested together with the plan record: one trip to memory)
         if (__builtin_amdgcn_readfirstlane(only_fallback[page].flags) != PLAN_F_WHOLE) continue;
         __syncthreads();  // the previous page's LDS is done with
-        const pqd_page_desc d = descs[page];
         if (!dict_whole_page<ELEM>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) {
           __syncthreads();
           rle_page<ELEM, HAS_DICT>(descs, results, page, win4);

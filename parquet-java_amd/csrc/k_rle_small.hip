@@ -92,33 +92,34 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
   const pqd_page_desc d = descs[page];
   const uint32_t tid = threadIdx.x;
 
-  // ---- which pages: plain hybrid streams (with or without the 4-byte length / 1-byte width in front)
-  uint32_t pos = 0, end = d.data_len, w = d.bit_width, consumed_override = ~0u;
+  // ---- which pages: plain hybrid streams (with or without the 4-byte length / 1-byte width in front).  The prefix is
+  // requested here and looked at behind the loads of the staging step, which do not wait for it: they cover what the
+  // stream can be at most (the rest of the page, or RS_MAX_BYTES), and what lies behind its true end is cleared after.
+  uint32_t pos = 0, w = d.bit_width, consumed_override = ~0u;
   const uint32_t n_values = d.num_values;
   bool mine = d.encoding == PQD_ENC_RLE && d.elem_size == 4 && n_values != 0 && n_values <= RS_MAX_VALUES;
+  const PQD_GLOBAL uint8_t* gdata = (const PQD_GLOBAL uint8_t*)d.data;
+  uint32_t prefix = 0;
   if (mine && (d.flags & PQD_F_WIDTH_PREFIX)) {
-    mine = end != 0;
+    mine = d.data_len != 0;
     if (mine) {
-      w = d.data[0];
+      prefix = gdata[0];
       pos = 1;
     }
   } else if (mine && (d.flags & PQD_F_LENGTH_PREFIX)) {
-    mine = end >= 4;
+    mine = d.data_len >= 4;
     if (mine) {
-      const uint32_t len = (uint32_t)d.data[0] | ((uint32_t)d.data[1] << 8) | ((uint32_t)d.data[2] << 16) | ((uint32_t)d.data[3] << 24);
-      mine = (int32_t)len >= 0 && len <= end - 4;
+      prefix = (uint32_t)gdata[0] | ((uint32_t)gdata[1] << 8) | ((uint32_t)gdata[2] << 16) | ((uint32_t)gdata[3] << 24);
       pos = 4;
-      end = 4 + len;
-      consumed_override = end;
     }
   }
-  mine = mine && w >= 1 && w <= 8 && end - pos <= RS_MAX_BYTES && end > pos;
+  mine = mine && d.data_len > pos;
   if (!mine) {
     if (tid == 0) plans[page].flags = 0;
     return;
   }
-  const uint32_t N = end - pos;
-  const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.data + pos;
+  const uint32_t n_max = d.data_len - pos < RS_MAX_BYTES ? d.data_len - pos : RS_MAX_BYTES;
+  const PQD_GLOBAL uint8_t* src = gdata + pos;
 #ifdef PQD_PROF
   uint64_t stamp[10];
   int n_stamp = 0;
@@ -130,23 +131,50 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
 
   // ---- 1. the stream -> LDS (zeros behind it).  Whole aligned dwords are read (none lies wholly outside the page) and
   // shifted into place: a piece of 16 stream bytes is five independent loads, whatever the page's address.
+  constexpr int RS_PIECES = (RS_MAX_BYTES + 16 + RS_THREADS * 16 - 1) / (RS_THREADS * 16);  // 16-byte pieces per thread
+  const uint32_t off = (uint32_t)((uintptr_t)src & 3u), sh = off * 8u;
+  const PQD_GLOBAL uint32_t* wsrc = (const PQD_GLOBAL uint32_t*)((uintptr_t)src & ~(uintptr_t)3);
+  uint32_t x[RS_PIECES][5];
   {
-    const uintptr_t a = (uintptr_t)src;
-    const PQD_GLOBAL uint32_t* wsrc = (const PQD_GLOBAL uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t off = (uint32_t)(a & 3u), sh = off * 8u;
-    const uint32_t full = (off + N) >> 2;  // dwords wholly inside [aligned start, end of stream)
-    const uint32_t tail = (off + N) & 3u;  // stream bytes in dword `full`
-    for (uint32_t i = tid * 4u; i * 4u < N + 16u; i += RS_THREADS * 4u) {
-      uint32_t x[5];
+    const uint32_t words_max = (off + n_max + 3u) >> 2;  // dwords that hold a byte of what the stream can be at most
+#pragma unroll
+    for (int it = 0; it < RS_PIECES; ++it)
 #pragma unroll
       for (uint32_t k = 0; k < 5u; ++k) {
-        x[k] = 0u;
-        if (i + k < full)
-          x[k] = wsrc[i + k];
-        else if (i + k == full && tail)
-          x[k] = wsrc[i + k] & ((1u << (8u * tail)) - 1u);
+        const uint32_t i = tid * 4u + (uint32_t)it * (RS_THREADS * 4u) + k;
+        x[it][k] = i < words_max ? wsrc[i] : 0u;
       }
-      const u32x4 v = {funnel_shr(x[0], x[1], sh), funnel_shr(x[1], x[2], sh), funnel_shr(x[2], x[3], sh), funnel_shr(x[3], x[4], sh)};
+  }
+  uint32_t end = d.data_len;
+  if (d.flags & PQD_F_WIDTH_PREFIX) {
+    w = prefix;
+  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
+    mine = (int32_t)prefix >= 0 && prefix <= end - 4;
+    end = 4 + prefix;
+    consumed_override = end;
+  }
+  mine = mine && w >= 1 && w <= 8 && end - pos <= RS_MAX_BYTES && end > pos;
+  if (!mine) {
+    if (tid == 0) plans[page].flags = 0;
+    return;
+  }
+  const uint32_t N = end - pos;
+  {
+    const uint32_t full = (off + N) >> 2;  // dwords wholly inside [aligned start, end of stream)
+    const uint32_t tail = (off + N) & 3u;  // stream bytes in dword `full`
+#pragma unroll
+    for (int it = 0; it < RS_PIECES; ++it) {
+      const uint32_t i = tid * 4u + (uint32_t)it * (RS_THREADS * 4u);
+      if (i * 4u >= N + 16u) continue;
+#pragma unroll
+      for (uint32_t k = 0; k < 5u; ++k) {
+        if (i + k == full && tail)
+          x[it][k] &= (1u << (8u * tail)) - 1u;
+        else if (i + k >= full)
+          x[it][k] = 0u;
+      }
+      const u32x4 v = {funnel_shr(x[it][0], x[it][1], sh), funnel_shr(x[it][1], x[it][2], sh), funnel_shr(x[it][2], x[it][3], sh),
+                       funnel_shr(x[it][3], x[it][4], sh)};
       *reinterpret_cast<u32x4*>(pg + i * 4u) = v;
     }
   }

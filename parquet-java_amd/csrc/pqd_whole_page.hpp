@@ -186,10 +186,10 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
   const uint32_t tid = threadIdx.x;
   const uint32_t n_values = d.num_values;
   if (d.data_len < 2u || d.dict == nullptr) return false;
-  const uint32_t w = d.data[0];
   const uint32_t N = d.data_len - 1u;
-  if (!whole_page_candidate(N, n_values, w, d.dict_len, WP_MAX_BYTES)) return false;
-  const uint32_t vb = (w + 7u) >> 3;
+  if (N > WP_MAX_BYTES || n_values == 0u || n_values > WP_MAX_VALUES) return false;
+  // the width byte is requested here and looked at behind the staging step: one trip to memory for both
+  const uint32_t w = ((const PQD_GLOBAL uint8_t*)d.data)[0];
   const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.data + 1;
 
 #ifdef PQD_PROF
@@ -231,6 +231,8 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     L.rle_oob = 0u;
   }
   __syncthreads();
+  if (!whole_page_candidate(N, n_values, w, d.dict_len, WP_MAX_BYTES)) return false;  // (nothing but LDS was written)
+  const uint32_t vb = (w + 7u) >> 3;
   const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
 
   WP_STAMP();
