@@ -209,3 +209,56 @@ def test_gpu_damaged_regular_dictionary_pages(orc, elem, dict_path):
         assert st == ost and written == ovals.size, (i, cases[i][0], st, ost, written, ovals.size)
         assert (out.view(dt)[:written] == ovals).all(), i
         assert (guard == 0xA5).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elem", [4, 8])
+def test_gpu_run_heavy_dictionary_pages_damaged(orc, elem, monkeypatch):
+    """Run-heavy dictionary pages of random shape (the pages the left-over launch decodes whole: ids of 1..24 bits,
+    runs of random lengths, dictionaries shorter than the ids reach), as written and with a few bytes damaged, cut
+    short or followed by junk: status, count and values are the oracle's, and the consumed bytes are those of the
+    chunked path (PQD_WHOLE_MAX=0)."""
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(4100 + elem)
+    dt = np.int32 if elem == 4 else np.int64
+    pages, expect = [], []
+    for k in range(240):
+        w = int(rng.integers(1, 25))
+        reach = 1 << w
+        n_dict = int(min(reach, rng.integers(1, 70000))) if rng.random() < 0.8 else int(rng.integers(1, reach + 1) // 2 + 1)
+        dic = rng.integers(-(1 << 31), 1 << 31, n_dict).astype(dt)
+        n = int(rng.choice([1, 7, 8, 9, 500, 4096, 20000, 32768, int(rng.integers(1, 32769))]))
+        n_runs = int(rng.integers(1, max(n // int(rng.integers(9, 120)), 1) + 1))
+        ids = np.sort(rng.integers(0, reach, n_runs)).repeat(rng.integers(1, 2 * max(n // n_runs, 1) + 2, n_runs))[:n]
+        ids = np.concatenate([ids, np.full(n - ids.size, ids[-1])]).astype(np.int64)
+        if k % 5 == 0:  # not sorted: the runs in random order
+            cut = np.flatnonzero(np.diff(ids)) + 1
+            parts = np.split(ids, cut)
+            ids = np.concatenate([parts[i] for i in rng.permutation(len(parts))])
+        data = np.concatenate([np.array([w], np.uint8), orc.rle_encode(w, ids.astype(np.int32))])
+        kind = k % 4
+        if kind == 1 and data.size > 2:  # a few bytes damaged
+            data = data.copy()
+            hits = rng.integers(1, data.size, int(rng.integers(1, 4)))
+            data[hits] = rng.integers(0, 256, hits.size)
+        elif kind == 2:  # cut short
+            data = data[:int(rng.integers(1, data.size + 1))]
+        elif kind == 3 and k % 8 == 3:  # junk behind the stream
+            data = np.concatenate([data, rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)])
+        pages.append(gh.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+        expect.append(orc.dict_decode(data, dic, n))
+    results = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("PQD_WHOLE_MAX")
+        else:
+            monkeypatch.setenv("PQD_WHOLE_MAX", mode)
+        results[mode] = gh.decode_pages(pages)
+        for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(results[mode], expect)):
+            assert st == ost and written == ovals.size, (mode, i, st, ost, written, ovals.size)
+            assert (out.view(dt)[:written] == ovals).all(), (mode, i)
+            assert (guard == 0xA5).all(), (mode, i)
+    for i, (a, b) in enumerate(zip(results["0"], results[None])):
+        assert a[2] == b[2] or a[0] != 0, (i, a[2], b[2])  # bytes consumed (where the page decoded)
