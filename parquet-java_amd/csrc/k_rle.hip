@@ -418,8 +418,8 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
 }
 
 // Without a plan array: workgroup b decodes page b.  With one: only the pages the planned path could
-// not take are decoded here; the plan kernel has listed them (entry i of the list sits in
-// only_fallback[i].fallback_page, their number in *fallback_count), and the grid strides over the list.
+// not take are decoded here; the plan kernel has marked them in their plan records (only_fallback[page].flags) and set
+// the flag *fallback_count, and the grid strides over the records.
 // Dictionary pages with a plan: the same launch then expands the short chunks the sliced gather leaves
 // aside (pool != nullptr; pqd_expand.hpp), in the LDS the page decoder used.
 template <int ELEM, bool HAS_DICT>
@@ -441,29 +441,30 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
     if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x, win4);
     return;
   }
-  uint32_t n = *fallback_count;
-  if (n > n_pages) n = n_pages;
-  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t page = only_fallback[i].fallback_page;
-    if (page < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
-    __syncthreads();  // the next page reuses the LDS
-  }
-  if constexpr (HAS_DICT) {
-    // run-heavy pages the plan kernel left whole (PLAN_F_WHOLE): ids and lookups in one pass; what that routine does
-    // not cover is decoded by the page decoder above
-    if (pool && __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_WHOLE]) != 0u) {
-      static_assert(RLE_THREADS == WP_THREADS, "one workgroup shape for both parts");
-      for (uint32_t page = blockIdx.x; page < n_pages; page += gridDim.x) {
-        const pqd_page_desc d = descs[page];  // (requested together with the plan record: one trip to memory)
-        if (__builtin_amdgcn_readfirstlane(only_fallback[page].flags) != PLAN_F_WHOLE) continue;
-        __syncthreads();  // the previous page's LDS is done with
-        if (!dict_whole_page<ELEM>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) {
+  // Pages the plan kernel left to this launch are marked in their plan records (PLAN_F_FALLBACK: for the page decoder;
+  // PLAN_F_WHOLE: run-heavy dictionary pages, ids and lookups in one pass by dict_whole_page, and what that routine does
+  // not cover goes to the page decoder too).  Whether there are any is a flag in the counter block (a count kept with
+  // atomics made 20000 pages queue up for 200 us); workgroup b then looks at pages b, b + grid, ...
+  bool any = __builtin_amdgcn_readfirstlane(*fallback_count) != 0u;
+  if constexpr (HAS_DICT) any = any || (pool && __builtin_amdgcn_readfirstlane(cursor[PLAN_CTR_WHOLE]) != 0u);
+  if (any) {
+    static_assert(RLE_THREADS == WP_THREADS, "one workgroup shape for both parts");
+    for (uint32_t page = blockIdx.x; page < n_pages; page += gridDim.x) {
+      const pqd_page_desc d = descs[page];  // (requested together with the plan record: one trip to memory)
+      const uint32_t f = __builtin_amdgcn_readfirstlane(only_fallback[page].flags);
+      if (f != PLAN_F_FALLBACK && f != PLAN_F_WHOLE) continue;
+      __syncthreads();  // the previous page's LDS is done with
+      if constexpr (HAS_DICT) {
+        if (f == PLAN_F_WHOLE && pool) {
+          if (dict_whole_page<ELEM>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) continue;
           __syncthreads();
-          rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
         }
       }
-      __syncthreads();
+      rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
     }
+    __syncthreads();
+  }
+  if constexpr (HAS_DICT) {
     if (pool) {
       RleSeg* cs_buf = reinterpret_cast<RleSeg*>(win4);
       uint32_t* slow_list = reinterpret_cast<uint32_t*>(cs_buf + SEG_CHUNK);

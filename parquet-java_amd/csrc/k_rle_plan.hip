@@ -683,7 +683,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   if (not_planned) {
     if (tid == 0) {
       plans[page].flags = PLAN_F_FALLBACK;
-      plans[atomicAdd(cursor + 1, 1u)].fallback_page = page;  // the generic kernel's work list
+      cursor[PLAN_CTR_FALLBACK] = 1u;  // (a flag: the left-over launch then looks through the plan records)
       if (page < pool_chunks) write_empty_chunk(pool, page);
     }
     return;
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   if (tid == 0) {
     if (emitted == 0 && page < pool_chunks) write_empty_chunk(pool, page);
     plans[page].flags = fallback ? PLAN_F_FALLBACK : PLAN_F_DONE;
-    if (fallback) plans[atomicAdd(cursor + 1, 1u)].fallback_page = page;  // the generic kernel's work list
+    if (fallback) cursor[PLAN_CTR_FALLBACK] = 1u;  // (a flag: the left-over launch then looks through the plan records)
     if (!fallback) {
       pqd_page_result r;
       r.status = st.status;

@@ -15,7 +15,7 @@ hipError_t launch_unpack_run_i64(const uint8_t* in, uint64_t in_bytes, int64_t* 
                                  uint32_t w, hipStream_t stream);
 // elem: 4 or 8; has_dict: PQD_ENC_RLE_DICTIONARY pages
 // only_fallback_plans: nullptr = decode every page; else decode only pages whose plan is flagged for fallback
-// (the plan kernel lists those pages: entry i in plans[i].fallback_page, their number in *fallback_count)
+// (the plan kernel marks those pages in plans[page].flags and sets the flag *fallback_count)
 // (pool / pool_chunks / cursor: planned dictionary pages only: the same launch expands the short chunks that the
 // plan kernel took from the pool's end, DS_DIRECT_MAX in pqd_rle_plan.hpp, looking their ids up in memory)
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,

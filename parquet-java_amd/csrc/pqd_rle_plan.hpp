@@ -78,7 +78,7 @@ __host__ __device__ inline uint32_t plan_front_limit(uint32_t pool_chunks, uint3
 
 // The call's counter block (32-bit counters, zeroed per call):
 //   0  chunks asked for at the front of the pool's shared tail (behind the n_pages page slots; granted below plan_front_limit)
-//   1  pages left to the generic kernel (their list: RlePagePlan::fallback_page)
+//   1  non-zero: some page is left to the generic kernel (PLAN_F_FALLBACK in its plan record)
 //   2  plane slots claimed in this call (DictPlanes::list)
 //   3  non-zero: dictionary chunks that are neither regular nor listed exist (0: the batch takes the regular path
 //      of k_dict_pages_sliced)
@@ -160,12 +160,10 @@ __device__ inline void dict_plane_piece(const DictPlanes& planes, uint32_t item,
   }
 }
 
-// Per-page record of the plan kernel.  `flags` belongs to the page with that index; `fallback_page`
-// is a dense list: entry i names the i-th page left to the generic kernel (their number is counter 1
-// of the call's counter block).
+// Per-page record of the plan kernel.  `flags` belongs to the page with that index.
 struct RlePagePlan {
   uint32_t flags;          // PLAN_F_*
-  uint32_t fallback_page;
+  uint32_t reserved;
 };
 static_assert(sizeof(RlePagePlan) == 8, "plan record is 8 bytes");
 
