@@ -1104,7 +1104,7 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
   // PQD_WHOLE_MAX: dictionary pages with a stream of at most that many bytes, at most half of what their values would
   // take bit-packed, are decoded whole by the left-over launch (0: none)
   const char* wm = getenv("PQD_WHOLE_MAX");
-  const uint32_t whole_max = wm ? (uint32_t)atoi(wm) : WP_MAX_BYTES;
+  const uint32_t whole_max = wm ? (uint32_t)atoi(wm) : WP_MAX_STREAM;
   if (small) {  // small pages first: what it decodes the plan kernel skips
     hipError_t e = launch_rle_small_pages(descs, results, plans, n_pages, stream);
     if (e != hipSuccess) return e;

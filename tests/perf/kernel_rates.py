@@ -171,6 +171,12 @@ def main():
         return orc.dict_encode_ids(np.concatenate([x, np.full(20000 - x.size, x[-1], np.int32)]), 65536)
     run_pages("dictionary INT64, 65536 entries, sorted runs of ids, 5000 x 20000", sorted_runs, 5000, 20000, pq.ENC_RLE_DICTIONARY, 8,
               dictionary=dic)
+
+    def short_runs(r):  # runs of 1..20 equal ids, unsorted: a stream of ~15 KB per page, a dozen chunks of 231 segments
+        x = np.repeat(r.integers(0, 65536, 2400), r.integers(1, 21, 2400))[:20000].astype(np.int32)
+        return orc.dict_encode_ids(np.concatenate([x, np.full(20000 - x.size, x[-1], np.int32)]), 65536)
+    run_pages("dictionary INT64, 65536 entries, short runs of ids (1..20), 5000 x 20000", short_runs, 5000, 20000, pq.ENC_RLE_DICTIONARY, 8,
+              dictionary=dic)
     # delta binary packed timestamps
     for k in (4, 12, 20, 40):
         run_pages(f"DELTA_BINARY_PACKED INT64, deltas ~{k} bits, 5000 pages x 20000",

@@ -840,6 +840,22 @@ def test_dictionary_run_heavy_pages_decoded_whole(gpu, orc, monkeypatch, elem):
     body = orc.rle_encode(12, runs(8000, 4096, 200, 80))
     for value, n in ((0x9C40, 8600), (0x1234, 8600)):
         add(np.concatenate([np.array([12], np.uint8), body, np.array([600 << 1 & 0x7F | 0x80, 600 >> 6, value & 0xFF, value >> 8], np.uint8)]), n, d)
+    # streams of more than one 8 KiB window: short runs (about 14 KB); long bit-packed runs that cross the windows' ends
+    # between stretches of RLE runs; the same with an id beyond the dictionary in the third window and cut short there
+    big = dictionary(65536)
+    x = np.repeat(rng.integers(0, 65536, 2400), rng.integers(1, 21, 2400))[:20000].astype(np.int32)
+    add(orc.dict_encode_ids(np.concatenate([x, np.full(20000 - x.size, x[-1], np.int32)]), 65536), 20000, big)
+    mixed = np.concatenate([runs(6000, 65536, 150, 80), rng.integers(0, 65536, 5000), runs(8000, 65536, 200, 80),
+                            rng.integers(0, 65536, 5000), runs(8768, 65536, 200, 90)]).astype(np.int32)
+    page = orc.dict_encode_ids(mixed, 65536)
+    assert 16384 < page.size <= 32768
+    add(page, mixed.size, big)
+    add(page, 20001, big)  # the page ends inside the stream
+    mixed2 = mixed.copy()
+    mixed2[25000:25012] = 50000
+    page2 = orc.dict_encode_ids(mixed2, 65536)
+    add(page2, mixed2.size, d)  # 40000 entries: beyond the dictionary
+    add(page2[:20000], mixed2.size, d)
     good = orc.dict_encode_ids(runs(20000, 40000, 600, 70), 40000)
     add(good[:-1], 20000, d)  # the last run is cut off
     add(good[: good.size // 2], 20000, d)  # the stream ends short of the page
