@@ -10,10 +10,11 @@
 // 64-byte block leaves it, one thread hops over the blocks, every thread lists the runs of its block; a run table and a
 // bitmap of run starts then give every value its run by a popcount.  The dictionary is read from memory (L2): the ids of
 // such a page are few and close together.
-// Covered: streams of at most 8 KiB that are at most half of what the page's values would take bit-packed, at most 32768
-// values, id widths 1..24, run headers of up to three bytes.  Anything else, and every malformed stream (zero-length
-// runs, runs cut off by the end of the stream, a stream that ends short of the page's values), returns false with
-// nothing written: the caller decodes the page with the kernel that knows every rule of the reference.
+// Covered: streams of at most 32 KiB (taken through LDS a window of 8 KiB at a time) that are at most half of what the
+// page's values would take bit-packed, at most 32768 values, id widths 1..24, run headers of up to three bytes, runs
+// shorter than a window.  Anything else, and every malformed stream (zero-length
+// runs, runs cut off by the end of the stream, a stream that ends short of the page's values), returns false: the
+// caller decodes the page (again, where windows had been written) with the kernel that knows every rule of the reference.
 // Traffic: stream bytes in, ELEM bytes out per value; the dictionary entries come from L2.
 #pragma once
 
