@@ -2,7 +2,7 @@
 //
 // Follows RunLengthBitPackingHybridDecoder.readNext (parquet-column/.../values/rle/
 // RunLengthBitPackingHybridDecoder.java:80-109) for pages whose stream fits LDS: at most 8 KiB of runs,
-// at most 32768 values, bit widths 1..8.  That is every level page of a 20000-value data page, whose
+// at most 32768 values, bit widths 1..24.  That is every level page of a 20000-value data page, whose
 // streams are made of very short runs (an RLE run wherever eight equal levels meet, a few bit-packed
 // groups in between: a header every 10 to 20 values), so finding the headers is the work.
 // One workgroup of 256 threads per page:
@@ -37,16 +37,17 @@ constexpr uint32_t RS_GROUPS = RS_MAX_BYTES / RS_GROUP;
 static_assert(RS_GROUPS * RS_BLOCK == 4u * RS_THREADS, "four group chains per thread");
 constexpr uint32_t RS_MAX_VALUES = 32768;
 constexpr uint32_t RS_COMPLEX = 0xFFFFu, RS_END = 0xFFFEu;
-constexpr uint32_t RS_BIAS = 1u << 19;  // above first value * w (< 2^18)
+constexpr uint32_t RS_BIAS = 1u << 20;  // above first value * w (< 2^15 * 24)
+constexpr uint32_t RS_MAX_WIDTH = 24;
 
 struct SmallRun {
   uint32_t len, nvals, nb;
   bool packed, complex;
 };
 
-// The run whose header starts with the bytes `lo` (w in 1..8: an RLE value is one byte).  Headers of up
+// The run whose header starts with the bytes `lo`; vb = bytes of an RLE run's value.  Headers of up
 // to three bytes: counts below 2^20, which covers every run a page of 32768 values needs.
-__device__ __forceinline__ SmallRun small_run(uint32_t lo, uint32_t w) {
+__device__ __forceinline__ SmallRun small_run(uint32_t lo, uint32_t w, uint32_t vb) {
   SmallRun r;
   const uint32_t c0 = (lo >> 7) & 1u, c01 = c0 & (lo >> 15), c012 = c01 & (lo >> 23);
   const uint32_t h = (lo & 0x7Fu) | (c0 ? (lo >> 1) & 0x3F80u : 0u) | (c01 ? (lo >> 2) & 0x1FC000u : 0u);
@@ -54,7 +55,7 @@ __device__ __forceinline__ SmallRun small_run(uint32_t lo, uint32_t w) {
   r.nb = 1u + c0 + c01;
   r.packed = (h & 1u) != 0;
   r.complex = c012 != 0 || cnt == 0;
-  r.len = r.nb + (r.packed ? cnt * w : 1u);
+  r.len = r.nb + (r.packed ? cnt * w : vb);
   r.nvals = r.packed ? cnt * 8u : cnt;
   return r;
 }
@@ -153,12 +154,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     end = 4 + prefix;
     consumed_override = end;
   }
-  mine = mine && w >= 1 && w <= 8 && end - pos <= RS_MAX_BYTES && end > pos;
+  mine = mine && w >= 1 && w <= RS_MAX_WIDTH && end - pos <= RS_MAX_BYTES && end > pos;
   if (!mine) {
     if (tid == 0) plans[page].flags = 0;
     return;
   }
   const uint32_t N = end - pos;
+  const uint32_t vb = (w + 7u) >> 3;  // bytes of an RLE run's value
   {
     const uint32_t full = (off + N) >> 2;  // dwords wholly inside [aligned start, end of stream)
     const uint32_t tail = (off + N) & 3u;  // stream bytes in dword `full`
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
         const uint32_t p = (b0 + q) * RS_BLOCK + lane;  // blocks past n_blocks: positions past N, complex, never stored
         const uint32_t pw = p < N + 4u ? p >> 2 : 0u;  // (positions past the stream read its start: they are complex anyway)
         const uint32_t lo = funnel_shr(pgw[pw], pgw[pw + 1], (p & 3u) * 8u);
-        const SmallRun r = small_run(lo, w);
+        const SmallRun r = small_run(lo, w, vb);
         // where the run leads, counted from the block's first byte; RS_COMPLEX and RS_END are above every position
         to[q] = (r.complex || p + r.len > N) ? RS_COMPLEX : lane + r.len;
         if (p == N) to[q] = RS_END;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     uint32_t p = entry;
     while (p < block_end && p < N) {
       const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
-      const SmallRun r = small_run(lo, w);
+      const SmallRun r = small_run(lo, w, vb);
       ++my_runs;
       my_vals += r.nvals < RS_MAX_VALUES ? r.nvals : RS_MAX_VALUES;
       p += r.len;
@@ -306,11 +308,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rle_small_pages(const pqd_page_d
     uint32_t p = entry;
     while (p < block_end && p < N) {
       const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
-      const SmallRun r = small_run(lo, w);
+      const SmallRun r = small_run(lo, w, vb);
       if (val_i < n_values) {
         // table entry: bit 31 set = bit-packed, then bits 0..30 = RS_BIAS + stream bit of the run's first
-        // value - first value * w (value v of the run sits at entry + v * w - RS_BIAS); else the repeated value
-        runs[run_i] = r.packed ? (0x80000000u | (RS_BIAS + (p + r.nb) * 8u - val_i * w)) : (lo >> (8u * r.nb)) & 0xFFu;
+        // value - first value * w (value v of the run sits at entry + v * w - RS_BIAS); else the repeated value, its
+        // vb bytes as they are (the reference does not mask them to the width)
+        const uint32_t q = p + r.nb;
+        const uint32_t rep = funnel_shr(pgw[q >> 2], pgw[(q >> 2) + 1], (q & 3u) * 8u) & ((1u << (8u * vb)) - 1u);
+        runs[run_i] = r.packed ? (0x80000000u | (RS_BIAS + q * 8u - val_i * w)) : rep;
         atomicOr(&flags[val_i >> 5], 1u << (val_i & 31u));
         const uint32_t nv = r.nvals < RS_MAX_VALUES ? r.nvals : RS_MAX_VALUES;
         if (val_i + nv >= n_values) s_consumed = p + r.len;  // the run that holds the last value: read whole (:95-99)

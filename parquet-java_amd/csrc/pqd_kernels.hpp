@@ -31,7 +31,7 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
                                   const DictPlanes& planes, bool try_small, hipStream_t stream);
-// small plain hybrid pages (stream <= 8 KiB, <= 32768 values, widths 1..8) decoded whole; sets plans[page].flags
+// small plain hybrid pages (stream <= 8 KiB, <= 32768 values, widths 1..24) decoded whole; sets plans[page].flags
 // for every page (PLAN_F_SMALL_DONE where it decoded the page)
 hipError_t launch_rle_small_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t n_pages,
                                   hipStream_t stream);

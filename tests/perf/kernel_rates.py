@@ -177,6 +177,9 @@ def main():
         return orc.dict_encode_ids(np.concatenate([x, np.full(20000 - x.size, x[-1], np.int32)]), 65536)
     run_pages("dictionary INT64, 65536 entries, short runs of ids (1..20), 5000 x 20000", short_runs, 5000, 20000, pq.ENC_RLE_DICTIONARY, 8,
               dictionary=dic)
+    # the same two id streams decoded as ids (a BINARY column's readValueDictionaryId: the values are the ids)
+    run_pages("dictionary ids as INT32 (w=16), sorted runs, 5000 x 20000", sorted_runs, 5000, 20000, pq.ENC_RLE, 4, flags=pq.F_WIDTH_PREFIX)
+    run_pages("dictionary ids as INT32 (w=16), short runs (1..20), 5000 x 20000", short_runs, 5000, 20000, pq.ENC_RLE, 4, flags=pq.F_WIDTH_PREFIX)
     # delta binary packed timestamps
     for k in (4, 12, 20, 40):
         run_pages(f"DELTA_BINARY_PACKED INT64, deltas ~{k} bits, 5000 pages x 20000",
