@@ -10,9 +10,15 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-functi
 
 all: $(LIB) oracle cpptest
 
-$(LIB): $(SRCS) $(HDRS)
+# one object per source (make -j builds them side by side; a change to one kernel file rebuilds that file only)
+OBJS := $(patsubst $(CSRC)/%.hip,build/obj/%.o,$(SRCS))
+build/obj/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
 	@mkdir -p $(PKG)/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
 
 oracle:
 	$(MAKE) -s -C oracle libpqd_oracle.so

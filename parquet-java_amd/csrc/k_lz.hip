@@ -116,26 +116,35 @@ __device__ __forceinline__ bool snappy_window(InStage& in, OutRing& out, uint8_t
       out.dst[at] = v;
     }
   }
-  // a literal that goes on behind the window: the rest of it
+  // a literal that goes on behind the window (always the window's last element): what is left of it is moved
+  // AFTER the copies, whose ring slots it may take
+  uint32_t tail_from = 0, tail_op = 0, tail_len = 0;
   if (T) {
     const uint32_t l_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(T - 1u));
     const uint32_t l_meta = (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)(T - 1u));
     const uint32_t l_op = (uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)(T - 1u));
     const uint32_t first = l_pos + ((l_meta >> 28) & 7u), len = l_meta & 0x0FFFFFFFu;
     if ((l_meta >> 31) && first + len > 64u) {
-      const uint32_t done = first < 64u ? 64u - first : 0u;       // bytes moved above
-      const uint32_t from = first < 64u ? 64u : first;            // window position of the next one
-      out.literal(in, ip + from, l_op + done, len - done, 1900u);  // (ip + 64 + 1900 lies inside the staged chunks)
+      const uint32_t done = first < 64u ? 64u - first : 0u;  // bytes moved above
+      tail_from = first < 64u ? 64u : first;                 // window position of the next one
+      tail_op = l_op + done;
+      tail_len = len - done;
     }
   }
-  // ---- copies, in order
+  // ---- copies, in order.  The window's literal bytes are in the ring already, up to output position
+  // op + total - tail_len: a copy whose source slots lie a whole ring below a position written above reads
+  // its bytes back from memory instead (the slot of source byte s holds s + ring size by now).
+  const uint32_t written_end = op + total - tail_len;
   uint64_t copies = __builtin_amdgcn_ballot_w64(mine && !e_lit);
   while (copies) {
     const uint32_t i = (uint32_t)__builtin_ctzll(copies);
     copies &= copies - 1ull;
-    out.match((uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)i), (uint32_t)__builtin_amdgcn_readlane((int)e_off, (int)i),
-              (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)i) & 0x0FFFFFFFu);
+    const uint32_t c_op = (uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)i);
+    const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)e_off, (int)i);
+    out.match(c_op, c_off, (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)i) & 0x0FFFFFFFu,
+              c_off + (written_end - c_op) > out.ring_mask + 1u);
   }
+  if (tail_len) out.literal(in, ip + tail_from, tail_op, tail_len, 1900u);  // (ip + 64 + 1900 lies inside the staged chunks)
   op += total;
   ip = leave == SW_END ? in_end : ip + leave;
   return true;
@@ -319,12 +328,21 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
 }
 
 // stored bytes (an uncompressed codec, the level bytes of a V2 page, a V2 page with is_compressed = false)
+// A descriptor whose codec is neither that nor the codec of the call has no kernel in this launch sequence: it
+// gets PQD_BAD_ARG here, so that its result is never what the memory held before.
 __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc* __restrict__ descs,
-                                                      pqd_page_result* __restrict__ results, uint32_t n_pages) {
+                                                      pqd_page_result* __restrict__ results, uint32_t n_pages,
+                                                      uint32_t call_codec) {
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
-  if (d.codec != PQD_CODEC_UNCOMPRESSED) return;
+  if (d.codec != PQD_CODEC_UNCOMPRESSED) {
+    if (d.codec != call_codec && threadIdx.x == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
   const uint32_t n = d.src_len < d.dst_len ? d.src_len : d.dst_len;
   const uint32_t pieces = n >> 4;
   for (uint32_t i = threadIdx.x; i < pieces; i += 256u) {
@@ -353,7 +371,7 @@ hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_re
   if (codec == PQD_CODEC_ZSTD) {
     hipError_t ez = launch_zstd_pages(descs, results, n_pages, stream);
     if (ez != hipSuccess) return ez;
-    hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
     return hipGetLastError();
   }
   const char* v = getenv("PQD_LZ_RING");
@@ -366,7 +384,7 @@ hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_re
     launch_lz<16384u>(descs, results, n_pages, codec, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages);
+  hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
   return hipGetLastError();
 }
 

@@ -16,13 +16,15 @@ namespace pqd {
 
 constexpr int PLAIN_THREADS = 256;
 
+// (Pages run along grid.x, `per_page` workgroups each: grid.y and grid.z stop at 65 535 blocks, a batch does not.)
 __global__ __launch_bounds__(PLAIN_THREADS) void k_plain_pages(const pqd_page_desc* __restrict__ descs,
-                                                               pqd_page_result* __restrict__ results, uint32_t n_pages) {
-  const uint32_t page = blockIdx.y;
+                                                               pqd_page_result* __restrict__ results, uint32_t n_pages,
+                                                               uint32_t per_page) {
+  const uint32_t page = blockIdx.x / per_page, part = blockIdx.x % per_page;
   if (page >= n_pages) return;
   const pqd_page_desc d = descs[page];
   const uint32_t K = d.elem_size;
-  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  const bool lead = part == 0 && threadIdx.x == 0;
   if (d.encoding != PQD_ENC_PLAIN || K == 0 || K > 16) {
     if (lead) {
       pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
@@ -38,13 +40,13 @@ __global__ __launch_bounds__(PLAIN_THREADS) void k_plain_pages(const pqd_page_de
   // 16-byte pieces from any source address to any destination address (4-byte aligned accesses are
   // not required on this device; the pieces of a lane's neighbours are adjacent)
   const uint64_t pieces = bytes >> 4;
-  const uint64_t stride = (uint64_t)gridDim.x * PLAIN_THREADS;
-  for (uint64_t i = (uint64_t)blockIdx.x * PLAIN_THREADS + threadIdx.x; i < pieces; i += stride) {
+  const uint64_t stride = (uint64_t)per_page * PLAIN_THREADS;
+  for (uint64_t i = (uint64_t)part * PLAIN_THREADS + threadIdx.x; i < pieces; i += stride) {
     u32x4 v;
     __builtin_memcpy(&v, in + i * 16, 16);
     __builtin_memcpy(out + i * 16, &v, 16);
   }
-  if (blockIdx.x == 0) {
+  if (part == 0) {
     for (uint64_t b = (pieces << 4) + threadIdx.x; b < bytes; b += PLAIN_THREADS) out[b] = in[b];
   }
   if (lead) {
@@ -58,11 +60,11 @@ __global__ __launch_bounds__(PLAIN_THREADS) void k_plain_pages(const pqd_page_de
 template <int ELEM>
 __global__ __launch_bounds__(PLAIN_THREADS) void k_plain_boolean_pages(const pqd_page_desc* __restrict__ descs,
                                                                        pqd_page_result* __restrict__ results,
-                                                                       uint32_t n_pages) {
-  const uint32_t page = blockIdx.y;
+                                                                       uint32_t n_pages, uint32_t per_page) {
+  const uint32_t page = blockIdx.x / per_page, part = blockIdx.x % per_page;
   if (page >= n_pages) return;
   const pqd_page_desc d = descs[page];
-  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  const bool lead = part == 0 && threadIdx.x == 0;
   if (d.encoding != PQD_ENC_PLAIN_BOOLEAN || d.elem_size != ELEM) {
     if (lead) {
       pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(PLAIN_THREADS) void k_plain_boolean_pages(const pqd
   const uint8_t* in = d.data;
   // one input byte = eight values per lane and step
   const uint32_t n_bytes = (n + 7) >> 3;
-  const uint32_t stride = gridDim.x * PLAIN_THREADS;
-  for (uint32_t b = blockIdx.x * PLAIN_THREADS + threadIdx.x; b < n_bytes; b += stride) {
+  const uint32_t stride = per_page * PLAIN_THREADS;
+  for (uint32_t b = part * PLAIN_THREADS + threadIdx.x; b < n_bytes; b += stride) {
     const uint32_t x = in[b];
     const uint32_t first = b * 8;
     if (ELEM == 1) {
@@ -119,19 +121,20 @@ static uint32_t workgroups_per_page(uint32_t n_pages) {
 
 hipError_t launch_plain_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plain_pages, dim3(workgroups_per_page(n_pages), n_pages), dim3(PLAIN_THREADS), 0, stream, descs, results,
-                     n_pages);
+  const uint32_t per_page = workgroups_per_page(n_pages);
+  hipLaunchKernelGGL(k_plain_pages, dim3(per_page * n_pages), dim3(PLAIN_THREADS), 0, stream, descs, results, n_pages, per_page);
   return hipGetLastError();
 }
 
 hipError_t launch_plain_boolean_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                                       hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  const dim3 grid(workgroups_per_page(n_pages), n_pages), block(PLAIN_THREADS);
+  const uint32_t per_page = workgroups_per_page(n_pages);
+  const dim3 grid(per_page * n_pages), block(PLAIN_THREADS);
   if (elem == 1)
-    hipLaunchKernelGGL(k_plain_boolean_pages<1>, grid, block, 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL(k_plain_boolean_pages<1>, grid, block, 0, stream, descs, results, n_pages, per_page);
   else
-    hipLaunchKernelGGL(k_plain_boolean_pages<4>, grid, block, 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL(k_plain_boolean_pages<4>, grid, block, 0, stream, descs, results, n_pages, per_page);
   return hipGetLastError();
 }
 

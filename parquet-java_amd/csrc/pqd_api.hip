@@ -113,6 +113,8 @@ struct PlanScratch {
                                  // begins with a memset of its own (a launch of 5 us in front of a 17 us kernel).
   int which = 0;
   bool clean[2] = {false, false};  // the block was zeroed after its last use
+  bool captured = false;           // a call on this stream was captured into a graph: replays run outside this
+                                   // book-keeping, so from then on every call zeroes its block itself
   void* plane_area = nullptr;    // plane copies of 8-byte dictionaries, plane_slots x DP_SLOT_BYTES
   uint32_t plane_slots = 0;
 };
@@ -188,15 +190,21 @@ int plan_scratch_acquire(hipStream_t stream, uint32_t n_pages, uint32_t want_pla
 
 // The counter block of this call (zeroed here only if the call before did not get to do it) ...
 int counters_begin(PlanScratch& ps, hipStream_t s, uint32_t** counters, uint32_t** other) {
+  // A sequence captured into a graph is replayed any number of times, in an order the host state here knows
+  // nothing of: a captured call zeroes its block inside the sequence (as does every call after it).
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  PQD_HIP(hipStreamIsCapturing(s, &cap));
+  if (cap != hipStreamCaptureStatusNone) ps.captured = true;
   uint32_t* base = ps.counters + (size_t)ps.which * (COUNTER_BLOCK_BYTES / 4);
   *other = ps.counters + (size_t)(ps.which ^ 1) * (COUNTER_BLOCK_BYTES / 4);
-  if (!ps.clean[ps.which]) PQD_HIP(hipMemsetAsync(base, 0, COUNTER_BYTES + PLANE_KEYS_BYTES, s));
+  if (!ps.clean[ps.which] || ps.captured) PQD_HIP(hipMemsetAsync(base, 0, COUNTER_BYTES + PLANE_KEYS_BYTES, s));
   ps.clean[ps.which] = false;  // in use from now on
   *counters = base;
   return PQD_OK;
 }
 // ... and, once the call's last launch (which zeroes the other block) is enqueued, the switch to that block.
 void counters_end(PlanScratch& ps) {
+  if (ps.captured) return;  // a replay uses the block it was captured with: no switching any more
   ps.clean[ps.which ^ 1] = true;
   ps.which ^= 1;
 }
@@ -257,10 +265,15 @@ void HostCtx::release() {
 // Device address of `scratch` on the current device (looked up once per device, with that device
 // current: each GPU has its own copy of the array at its own address).
 constexpr int NOALLOC_MAX_DEVICES = 64;
-std::mutex g_noalloc_mutex;  // guards the table; also held while a call's launches are enqueued
+std::mutex g_noalloc_mutex;  // guards the tables; also held while a call's launches are enqueued
 unsigned char* g_noalloc_ptr[NOALLOC_MAX_DEVICES];
+// Calls on different streams of one GPU share that GPU's array, so they are ordered on the device: every call
+// records this event behind its last launch and the next call's stream waits for it first (created with the
+// address look-up, once per device; no allocation on the call path).
+hipEvent_t g_noalloc_done[NOALLOC_MAX_DEVICES];
+bool g_noalloc_recorded[NOALLOC_MAX_DEVICES];
 
-int noalloc_scratch(unsigned char** out) {
+int noalloc_scratch(unsigned char** out, int* dev_out = nullptr) {
   int dev = 0;
   PQD_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(PQD_BAD_ARG, "device index beyond the library's table");
@@ -268,9 +281,12 @@ int noalloc_scratch(unsigned char** out) {
     void* p = nullptr;
     PQD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     if (!p) return fail(PQD_HIP_ERROR, "hipGetSymbolAddress returned no address for the scratch array");
+    PQD_HIP(hipEventCreateWithFlags(&g_noalloc_done[dev], hipEventDisableTiming));
+    g_noalloc_recorded[dev] = false;
     g_noalloc_ptr[dev] = static_cast<unsigned char*>(p);
   }
   *out = g_noalloc_ptr[dev];
+  if (dev_out) *dev_out = dev;
   return PQD_OK;
 }
 
@@ -723,10 +739,19 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
   if (encoding == PQD_ENC_RLE_DICTIONARY && elem_size != 4 && elem_size != 8)
     return fail(PQD_BAD_ARG, "dictionary values must be 4 or 8 bytes");
   hipStream_t s = as_stream(stream);
-  std::lock_guard<std::mutex> lock(g_noalloc_mutex);  // one launch sequence at a time reaches the streams
+  // One launch sequence at a time is enqueued (the mutex), and one at a time runs (the event): a call on
+  // another stream starts only when the call before it has left the array.  A stream under graph capture
+  // takes no part in that (an event recorded outside the capture cannot be waited for inside it): replays of
+  // such a graph must not overlap other calls on the same GPU.
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
   unsigned char* base;
-  int st = noalloc_scratch(&base);
+  int dev = 0;
+  int st = noalloc_scratch(&base, &dev);
   if (st) return st;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  PQD_HIP(hipStreamIsCapturing(s, &cap));
+  const bool ordered = cap == hipStreamCaptureStatusNone;
+  if (ordered && g_noalloc_recorded[dev]) PQD_HIP(hipStreamWaitEvent(s, g_noalloc_done[dev], 0));
   void* pool = base;
   void* plans = base + NOALLOC_POOL_BYTES;
   uint32_t* counters = reinterpret_cast<uint32_t*>(base + NOALLOC_POOL_BYTES + NOALLOC_PLANS_BYTES);
@@ -745,6 +770,10 @@ int pqd_decode_pages_dev_noalloc(const pqd_page_desc* descs, pqd_page_result* re
   } else
     PQD_HIP(pqd::launch_rle_expand(pool, pool_chunks, counters, n_pages, s));
   PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, elem_size, dict, plans, counters + 1, s, dict ? pool : nullptr, pool_chunks, counters));
+  if (ordered) {
+    PQD_HIP(hipEventRecord(g_noalloc_done[dev], s));
+    g_noalloc_recorded[dev] = true;
+  }
   return PQD_OK;
 }
 
@@ -1062,7 +1091,7 @@ int pqd_decompress_pages_dev(const pqd_decompress_desc* descs, pqd_page_result* 
                              void* stream) {
   if (n_pages == 0) return PQD_OK;
   if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
-  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (UNCOMPRESSED, SNAPPY, GZIP, LZ4_RAW, ZSTD are)");
   PQD_HIP(pqd::launch_decompress_pages(descs, results, n_pages, codec, as_stream(stream)));
   return PQD_OK;
 }
@@ -1073,7 +1102,7 @@ int pqd_chunk_decompress_dev(const uint8_t* chunk, const pqd_chunk_page* pages, 
   if (n_pages == 0) return PQD_OK;
   if (!chunk || !pages || !bodies || !uncompressed_pages || !descs || !results)
     return fail(PQD_BAD_ARG, "null chunk / page table / output");
-  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (UNCOMPRESSED, SNAPPY, GZIP, LZ4_RAW, ZSTD are)");
   static thread_local std::vector<pqd_decompress_desc> host;
   host.assign((size_t)n_pages * 2, pqd_decompress_desc{});
   size_t at = 0;
@@ -1112,7 +1141,7 @@ int pqd_decompress_page(int codec, const uint8_t* src, uint32_t src_len, uint8_t
                         pqd_page_result* result) {
   if (!result) return fail(PQD_BAD_ARG, "null result");
   if ((src_len && !src) || (dst_len && !dst)) return fail(PQD_BAD_ARG, "null source / destination");
-  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (SNAPPY, LZ4_RAW, UNCOMPRESSED are)");
+  if (!pqd_codec_supported(codec)) return fail(PQD_BAD_ARG, "codec not supported (UNCOMPRESSED, SNAPPY, GZIP, LZ4_RAW, ZSTD are)");
   int st = check_device_available();
   if (st) return st;
   HostCtx& c = g_ctx;

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256) void k_chunk_sections(const pqd_chunk_page* __
   const uint32_t size = pg.uncompressed_size;
   const uint32_t n = pg.num_values;
   const uint32_t lbase = o.level_base ? o.level_base[i] : 0u;
-  int32_t status = PQD_OK;
+  // The records describe UNCOMPRESSED bodies (the walk's records of an uncompressed column, or the records
+  // pqd_chunk_decompress_dev returns): a record whose two sizes differ has only compressed_size bytes behind it.
+  int32_t status = pg.compressed_size == pg.uncompressed_size ? PQD_OK : PQD_DECODE;
   uint32_t pos = 0;
   pqd_page_desc lv[2];
   // repetition levels first, then definition levels (readPageV1 :734-744, readPageV2 :770-777)

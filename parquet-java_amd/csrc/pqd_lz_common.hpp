@@ -112,7 +112,8 @@ struct OutRing {
       }
     }
   }
-  __device__ __forceinline__ void match(uint32_t op, uint32_t offset, uint32_t len) {
+  // `from_memory`: the caller knows that the ring no longer holds the source bytes (offset of 64 or more)
+  __device__ __forceinline__ void match(uint32_t op, uint32_t offset, uint32_t len, bool from_memory = false) {
     uint32_t lm = lane;  // lane mod offset for offsets below 64: six conditional subtractions
     if (offset < 64u) {
 #pragma unroll
@@ -121,7 +122,7 @@ struct OutRing {
         lm = lm >= t ? lm - t : lm;
       }
     }
-    if (offset <= ring_mask + 1u) {
+    if (offset <= ring_mask + 1u && !from_memory) {
       for (uint32_t b = 0; b < len; b += 64u) {
         if (b + lane < len) {
           const uint8_t v = ring[(op + b + lm - offset) & ring_mask];

@@ -103,6 +103,39 @@ def handmade_snappy():
     return varint(len(out)) + b"".join(parts), bytes(out)
 
 
+def handmade_snappy_far_copies():
+    """(stream, original): copies from far back right in front of long literals, and copies from about a ring
+    size back in front of short ones.  A decoder that keeps the last 8 / 16 KiB of output in a ring and writes
+    an element's literal bytes into it before it has run the copies in front of them reads the wrong bytes here."""
+    rng = np.random.default_rng(55)
+    parts, out = [], bytearray()
+
+    def add_lit(b):
+        n = len(b) - 1
+        parts.append((bytes([n << 2]) if n < 60 else bytes([60 << 2, n]) if n < 256 else
+                      bytes([61 << 2]) + n.to_bytes(2, "little") if n < 65536 else bytes([62 << 2]) + n.to_bytes(3, "little")) + b)
+        out.extend(b)
+
+    def add_copy(offset, length):
+        parts.append(bytes([2 | ((length - 1) << 2)]) + offset.to_bytes(2, "little"))
+        for _ in range(length):
+            out.append(out[-offset])
+
+    text = (b"the quick brown fox jumps over the lazy dog; " * 400)[:17000]
+    add_lit(text)
+    for offset, tail in ((12000, 6000), (16000, 3000), (8000, 9000), (16384, 700), (8192, 64), (7000, 1500),
+                         (16380, 40), (8190, 30), (16300, 5), (8100, 5)):
+        add_copy(offset, 64)
+        add_copy(offset, 37)
+        add_lit(bytes(rng.integers(0, 256, tail, dtype=np.uint8)))
+        add_copy(offset // 2, 50)
+        for _ in range(6):  # short elements, so that one 64-byte window of input holds several of them
+            add_copy(offset - 11, 9)
+            add_lit(bytes(rng.integers(0, 256, 3, dtype=np.uint8)))
+        add_lit(text[:2000])
+    return varint(len(out)) + b"".join(parts), bytes(out)
+
+
 def handmade_lz4():
     rng = np.random.default_rng(6)
     parts, out = [], bytearray()
@@ -212,7 +245,8 @@ def live_zstd_streams():
 
 def test_oracle_handmade_streams(orc):
     import pyarrow as pa
-    for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("LZ4_RAW", handmade_lz4()), ("ZSTD", handmade_zstd())):
+    for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("SNAPPY", handmade_snappy_far_copies()),
+                                 ("LZ4_RAW", handmade_lz4()), ("ZSTD", handmade_zstd())):
         st, out, used = orc.decompress(codec, stream, len(raw))
         assert st == 0 and bytes(out) == raw and used == len(stream)
         if codec != "ZSTD":  # (the library's one-shot call stops after the first frame)
@@ -334,6 +368,51 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
     # announced sizes that do not fit the stream
     wrong = [(s, size + 1) for s, size in items[:8]] + [(s, size - 1) for s, size in items[:8] if size]
     check_batch(orc, codec_name, wrong, run_batch(pq, gh, torch, CODEC_NUM[codec_name], wrong))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring_kib", [None, "8", "32"])
+def test_gpu_snappy_far_copies_in_front_of_literals(orc, monkeypatch, ring_kib):
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    if ring_kib:
+        monkeypatch.setenv("PQD_LZ_RING", ring_kib)
+    stream, raw = handmade_snappy_far_copies()
+    assert orc.decompress("SNAPPY", stream, len(raw))[1].tobytes() == raw
+    items = [(stream, len(raw))] * 3
+    for misalign in (0, 5):
+        for st, data, used in run_batch(pq, gh, torch, CODEC_NUM["SNAPPY"], items, misalign):
+            assert st == 0 and used == len(stream)
+            assert data == raw
+
+
+@pytest.mark.gpu
+def test_gpu_descriptor_of_another_codec_is_rejected(orc):
+    """A batch is one codec plus stored parts: a descriptor that names another codec gets PQD_BAD_ARG, not what
+    the result array held before."""
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    snappy, raw = handmade_snappy()
+    lz4, raw4 = handmade_lz4()
+    n = 3
+    descs = (pq.DecompressDesc * n)()
+    streams = [(snappy, len(raw), CODEC_NUM["SNAPPY"]), (lz4, len(raw4), CODEC_NUM["LZ4_RAW"]), (b"stored", 6, 0)]
+    keep = []
+    for i, (stream, size, codec) in enumerate(streams):
+        src, dst = gh.to_dev(np.frombuffer(stream, np.uint8)), torch.zeros(size + 16, dtype=torch.uint8, device=gh.dev())
+        keep += [src, dst]
+        descs[i].src, descs[i].dst, descs[i].src_len, descs[i].dst_len, descs[i].codec = src.data_ptr(), dst.data_ptr(), len(stream), size, codec
+    d_descs = gh.to_dev(np.frombuffer(bytes(descs), np.uint8).copy())
+    for call_codec, want in ((CODEC_NUM["SNAPPY"], [0, pq.BAD_ARG, 0]), (CODEC_NUM["LZ4_RAW"], [pq.BAD_ARG, 0, 0]),
+                             (0, [pq.BAD_ARG, pq.BAD_ARG, 0]), (CODEC_NUM["ZSTD"], [pq.BAD_ARG, pq.BAD_ARG, 0])):
+        d_res = torch.full((n * 16,), 0x77, dtype=torch.uint8, device=gh.dev())
+        pq.check(pq.lib.pqd_decompress_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n, call_codec, None))
+        torch.cuda.synchronize()
+        assert d_res.cpu().numpy().view(np.int32).reshape(-1, 4)[:, 0].tolist() == want
 
 
 @pytest.mark.gpu

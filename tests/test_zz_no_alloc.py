@@ -126,3 +126,47 @@ def test_no_alloc_entry_limits_and_pass_through(orc, monkeypatch):
     a = run(pq, gh, torch, delta, noalloc)
     same(a, run(pq, gh, torch, delta, alloc))
     assert (a[2][:ts.nbytes].view(np.int64) == ts).all()
+
+
+def test_no_alloc_calls_on_two_streams_queue_up(orc):
+    """Calls on different streams of one GPU share the GPU's scratch array: the library orders them on the
+    device (an event behind every call), so both produce what they produce alone."""
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(99)
+    noalloc, alloc = pq.lib.pqd_decode_pages_dev_noalloc, pq.lib.pqd_decode_pages_dev
+    batches = [dictionary_pages(pq, gh, orc, rng, 400, 8, 60_000), dictionary_pages(pq, gh, orc, rng, 350, 4, 40_000),
+               level_pages(pq, gh, orc, rng, 300), dictionary_pages(pq, gh, orc, rng, 64, 8, 60_000)]
+    want = [run(pq, gh, torch, b, alloc) for b in batches]
+    # the same batches, enqueued back to back on alternating streams with no host wait in between
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    prepared = []
+    for b in batches:
+        enc, elem = b[0].encoding, b[0].elem_size
+        blob = np.concatenate([np.full(1, 0xEE, np.uint8)] + [p.data for p in b] + [np.full(64, 0xEE, np.uint8)])
+        d_blob = gh.to_dev(blob)
+        offs = np.cumsum([1] + [p.data.size for p in b])[:-1]
+        out_offs = np.cumsum([0] + [((p.num_values * elem + 15) & ~15) + 16 for p in b])
+        d_out = torch.full((int(out_offs[-1]) + 16,), 0xA5, dtype=torch.uint8, device=gh.dev())
+        dicts, descs = {}, []
+        for p, o, oo in zip(b, offs, out_offs):
+            dd = dl = 0
+            if p.dictionary is not None:
+                if id(p.dictionary) not in dicts:
+                    dicts[id(p.dictionary)] = gh.to_dev(p.dictionary.view(np.uint8))
+                dd, dl = dicts[id(p.dictionary)].data_ptr(), p.dictionary.size
+            descs.append(dict(data=d_blob.data_ptr() + int(o), out=d_out.data_ptr() + int(oo), dict=dd, data_len=p.data.size,
+                              num_values=p.num_values, dict_len=dl, encoding=enc, elem_size=elem, bit_width=p.bit_width,
+                              flags=p.flags))
+        d_descs = gh.to_dev(pq.descs_to_numpy(pq.make_descs(descs)))
+        d_res = torch.zeros(len(b) * 16, dtype=torch.uint8, device=gh.dev())
+        prepared.append((d_blob, dicts, d_descs, d_res, d_out, len(b), enc, elem))
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        for k, (d_blob, dicts, d_descs, d_res, d_out, n, enc, elem) in enumerate(prepared):
+            assert noalloc(d_descs.data_ptr(), d_res.data_ptr(), n, enc, elem, streams[k % 2].cuda_stream) == 0
+    torch.cuda.synchronize()
+    for (d_blob, dicts, d_descs, d_res, d_out, n, enc, elem), w in zip(prepared, want):
+        same((0, pq.results_from_numpy(d_res.cpu().numpy()), d_out.cpu().numpy()), w)
