@@ -221,6 +221,55 @@ def config1_sweep(device, stream, timed, n_pages=256, n_values=1_000_000):
             "note": "algorithmic bytes = encoded page + 4 bytes per value; distinct pages (2.0 GiB decoded per call: beyond the 256 MiB Infinity Cache)"}
 
 
+def config5_shard(device, stream, timed, rank=0):
+    """BASELINE.json configs[4], one GPU's share: 512 row groups x 20 mixed-encoding column chunks dealt round
+    robin over 8 GPUs = 64 row groups x 20 chunks x 250 000 values here (dictionary INT32 / INT64, DELTA_BINARY_PACKED,
+    BYTE_STREAM_SPLIT DOUBLE, definition levels on half of the columns), pages built on the device.  Timed twice:
+    one pqd_decode_pages_dev call per encoding class over the whole share (device descriptors, events), and row
+    group by row group through shard.decode_row_groups (host descriptors, one pqd_decode_pages call and one host
+    wait per row group: wall clock)."""
+    import synth_pages as sp
+    from parquet_java_amd.shard import assign_row_groups, decode_row_groups
+    owned = assign_row_groups([1] * 512, 8)[rank % 8]
+    shard = sp.build_mixed_shard(pq, device, owned)
+    calls, enc_bytes, out_bytes, values = [], 0, 0, 0
+    for name, c in shard.items():
+        d_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(sp.shard_page_descs(c, 0, c["n_pages"])))).to(device)
+        d_res = torch.zeros(c["n_pages"] * 16, dtype=torch.uint8, device=device)
+        calls.append((name, d_descs, d_res, c))
+        enc_bytes += int(c["offs"][-1])
+        out_bytes += c["n_pages"] * c["page_values"] * c["elem"]
+        values += c["n_pages"] * c["page_values"]
+
+    def run():
+        for name, d_descs, d_res, c in calls:
+            pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), c["n_pages"], c["encoding"], c["elem"], stream)
+    ms = timed(run, iters=5)
+    ok = True
+    per_class = {}
+    for name, d_descs, d_res, c in calls:
+        status, written, _ = pq.results_from_numpy(d_res.cpu().numpy())
+        ok = ok and bool((status == 0).all() and (written == c["page_values"]).all()) and c["expect"]()
+        one = lambda: pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), c["n_pages"], c["encoding"], c["elem"], stream)  # noqa: E731
+        per_class[name] = round(timed(one, iters=3), 4)
+    for c in shard.values():
+        c["out"].zero_()
+    groups = {g: pq.make_descs(sp.shard_row_group_descs(shard, k)) for k, g in enumerate(owned)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = decode_row_groups(groups, rank % 8, 8, stream, [1] * 512)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ok = ok and all(not s["failed"] for _, s in done.values()) and all(c["expect"]() for c in shard.values())
+    alg = enc_bytes + out_bytes
+    return {"row_groups": len(owned), "chunks_per_row_group": 20, "values_per_chunk": 250_000, "pages": sum(c["n_pages"] for c in shard.values()),
+            "values_incl_levels": values, "decoded_bytes": out_bytes, "encoded_bytes": enc_bytes,
+            "ms_one_call_per_encoding_class": round(ms, 4), "decoded_GBps": round(out_bytes / ms / 1e6, 1),
+            "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
+            "ms_per_class_alone": per_class,
+            "ms_row_group_by_row_group_host_calls": round(wall_ms, 2), "verified": bool(ok)}
+
+
 def sources_digest():
     """sha256 over the kernel sources (the same function as in tools/pmc_traffic.py)."""
     import hashlib
@@ -478,6 +527,7 @@ def main():
             "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
             "page_bytes": r_len, "runs_per_page": 500, "verified": ok}
         del r_blob, r_ids
+        extras["config5_shard"] = config5_shard(device, stream, timed, rank)
         if not args.no_config1:
             for c in cols:  # make room: the columns of the timed region are no longer needed
                 c["out"] = c["blob"] = c["ids"] = None
