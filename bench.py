@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: device-resident decode of dictionary-encoded pages (RLE/bit-packed hybrid ids).
 
-Workload (BASELINE.json configs[1], per GPU): 100 M rows of a dictionary-encoded INT32 column and 100 M
-rows of a dictionary-encoded INT64 column, 65 536-entry dictionaries (id width 16), 5 000 pages of
-20 000 values each per column (parquet-java's default page row limit), ids written as parquet-java
-writes them: 1-byte bit width, then bit-packed runs of at most 504 values with 1-byte headers.
-One step = one decode pass over both columns (per column: run-plan kernel, sliced gather kernel,
-and the generic kernel for pages the plan leaves to it - none in this workload).  Pages, dictionaries and
-outputs are resident in HBM before the timed region starts.
+Workload (BASELINE.json configs[1], per GPU): 100 M rows each of a dictionary-encoded INT32 column, a
+dictionary-encoded INT64 column and a dictionary-encoded BINARY column (entries of 4..12 bytes), 65 536-entry
+dictionaries (id width 16), 5 000 pages of 20 000 values each per column (parquet-java's default page row limit),
+ids written as parquet-java writes them: 1-byte bit width, then bit-packed runs of at most 504 values with 1-byte
+headers.  One step = one decode pass over the three columns (INT32 / INT64: run-plan kernel, sliced gather kernel,
+and the generic kernel for pages the plan leaves to it - none in this workload; BINARY: one kernel, ids ->
+offsets + bytes).  Pages, dictionaries and outputs are resident in HBM before the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -116,6 +116,64 @@ def make_descs(blob, page_len, dictionary, out, elem, device, encoding=None, fla
     d_descs = torch.from_numpy(pq.descs_to_numpy(arr)).to(device)
     d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
     return d_descs, d_res
+
+
+def build_binary_column(cols_like, n_pages, device, seed=77):
+    """The BINARY column: a dictionary page of DICT_ENTRIES entries of 4..12 random bytes ([length LE32][bytes] ...,
+    about 768 KiB), its handle, and per page offsets[PAGE_VALUES + 1] + bytes outputs.  The id pages are those of
+    `cols_like` (an id column built by build_column)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(4, 13, DICT_ENTRIES)
+    body = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
+    page = np.zeros(int(lens.sum()) + 4 * DICT_ENTRIES, np.uint8)
+    starts = np.cumsum(lens + 4) - lens
+    for k in range(4):
+        page[starts - 4 + k] = (lens >> (8 * k)) & 0xFF
+    dst = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(body.size)
+    page[dst] = body
+    handle = C.c_void_p()
+    pq.check(pq.lib.pqd_dict_create(pq.TYPE_BYTE_ARRAY, 0, page.ctypes.data_as(C.c_void_p), page.size, DICT_ENTRIES,
+                                    C.byref(handle)))
+    info = pq.DictInfo()
+    pq.check(pq.lib.pqd_dict_get(handle, C.byref(info)))
+    c = cols_like
+    cap = PAGE_VALUES * 12
+    b_offsets = torch.zeros((n_pages, PAGE_VALUES + 1), dtype=torch.int32, device=device)
+    b_bytes = torch.zeros((n_pages, cap), dtype=torch.uint8, device=device)
+    pages = [dict(data=c["blob"].data_ptr() + i * c["page_len"], dict=info.entries, data_len=c["page_len"], num_values=PAGE_VALUES,
+                  dict_len=DICT_ENTRIES, encoding=pq.ENC_RLE_DICTIONARY, elem_size=8) for i in range(n_pages)]
+    bd = (pq.BinaryPageDesc * n_pages)()
+    for i in range(n_pages):
+        bd[i].dict_bytes = info.bytes
+        bd[i].offsets = b_offsets.data_ptr() + i * (PAGE_VALUES + 1) * 4
+        bd[i].bytes = b_bytes.data_ptr() + i * cap
+        bd[i].num_values = PAGE_VALUES
+        bd[i].dict_bytes_len = info.bytes_len
+        bd[i].bytes_capacity = cap
+    return dict(handle=handle, info=info, lens=lens, starts=starts, page=page, cap=cap, offsets=b_offsets, bytes=b_bytes,
+                pages=pages, bd=bd, page_descs=torch.from_numpy(pq.descs_to_numpy(pq.make_descs(pages))).to(device),
+                bin_descs=torch.from_numpy(np.frombuffer(bytes(bd), np.uint8).copy()).to(device),
+                page_res=torch.zeros(n_pages * 16, dtype=torch.uint8, device=device),
+                bin_res=torch.zeros(n_pages * 16, dtype=torch.uint8, device=device), ids=c["ids"], page_len=c["page_len"])
+
+
+def verify_binary(b, device, chk):
+    """Results of every page, and offsets + bytes of the first `chk` pages rebuilt with torch."""
+    st_p, wr_p, _ = pq.results_from_numpy(b["page_res"].cpu().numpy())
+    st_b, wr_b, nb_b = pq.results_from_numpy(b["bin_res"].cpu().numpy())
+    ok = bool((st_b == 0).all() and (wr_b == PAGE_VALUES).all() and (st_p == 0).all() and (wr_p == PAGE_VALUES).all())
+    t_lens = torch.from_numpy(b["lens"]).to(device)
+    t_starts = torch.from_numpy(b["starts"]).to(device)
+    t_page = torch.from_numpy(b["page"]).to(device)
+    ids_chk = b["ids"][:chk].long()
+    l_chk = t_lens[ids_chk]
+    exp_off = torch.zeros((chk, PAGE_VALUES + 1), dtype=torch.int64, device=device)
+    exp_off[:, 1:] = torch.cumsum(l_chk, 1)
+    ok = ok and bool(torch.equal(exp_off.to(torch.int32), b["offsets"][:chk]))
+    for i in range(chk):
+        src = torch.repeat_interleave(t_starts[ids_chk[i]] - exp_off[i, :-1], l_chk[i]) + torch.arange(int(exp_off[i, -1]), device=device)
+        ok = ok and bool(torch.equal(t_page[src], b["bytes"][i, :int(exp_off[i, -1])]))
+    return ok, int(nb_b.astype(np.int64).sum())
 
 
 class Event:
@@ -313,6 +371,8 @@ def main():
     ap.add_argument("--pages", type=int, default=5000, help="pages per column per GPU (5000 x 20000 = 100 M rows)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--warm-ms", type=float, default=60.0,
+                    help="the warm-up lasts at least this long: after the --warmup steps, further untimed steps run until then")
     ap.add_argument("--no-config1", action="store_true", help="skip the 32-width sweep of 1 M-value hybrid pages in extras")
     ap.add_argument("--no-extras", action="store_true",
                     help="the timed workload only (profiler passes: every launch of a kernel in the trace then belongs to it)")
@@ -347,16 +407,28 @@ def main():
         d_descs, d_res = make_descs(blob, page_len, dictionary, out, elem, device)
         cols.append(dict(elem=elem, blob=blob, page_len=page_len, ids=ids, dictionary=dictionary, out=out,
                          descs=d_descs, res=d_res))
+    # the BINARY column: id pages of its own, a dictionary of 4..12-byte entries, offsets + bytes per page
+    blob, page_len, ids, _, _ = build_column(args.pages, 4, 1234 + 17 * rank + 12, device)
+    binary = build_binary_column(dict(blob=blob, page_len=page_len, ids=ids), args.pages, device)
+    binary["blob"] = blob
     torch.cuda.synchronize()
 
-    def step():
-        for c in cols:
-            pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY,
-                                c["elem"], stream)
+    def decode_fixed(c):
+        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, c["elem"], stream)
 
-    # the check against a torch gather comes first, the warm-up steps directly in front of the timed region: the
+    def decode_binary():
+        pq.check(pq.lib.pqd_decode_binary_pages_dev(binary["handle"], binary["page_descs"].data_ptr(), binary["bin_descs"].data_ptr(),
+                                                    binary["page_res"].data_ptr(), binary["bin_res"].data_ptr(), args.pages, stream))
+
+    def step():
+        decode_fixed(cols[0])
+        decode_fixed(cols[1])
+        decode_binary()
+
+    # the check against torch comes first, the warm-up steps directly in front of the timed region: the
     # check leaves the GPU idle while the host compares, and the first steps after an idle spell run 5-8 % slower
     verified = None
+    binary_bytes = None
     if not args.no_verify:
         step()
         torch.cuda.synchronize()
@@ -368,30 +440,48 @@ def main():
             ok = ok and bool(torch.equal(expect, c["out"]))
             verified = verified and bool(ok)
             del expect
+        ok, binary_bytes = verify_binary(binary, device, min(args.pages, 64))
+        verified = verified and ok
         for c in cols:
             c["out"].zero_()
         torch.cuda.synchronize()
+    if binary_bytes is None:
+        binary_bytes = int(torch.from_numpy(binary["lens"]).to(device)[binary["ids"].long()].sum().item())
 
+    # W warm-up steps as asked for, then further untimed steps until the warm-up has lasted WARM_MS of device work: the
+    # clocks settle over some tens of milliseconds of load, whatever the number of steps that takes
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    extra_warm = 0
+    while (time.perf_counter() - t_warm) * 1e3 < args.warm_ms:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        extra_warm += 4
 
-    # ---- timed region: exactly `steps` steps between barriers.  The library brackets the gather launch
-    # of every INT64 call with two HIP events on the stream it runs on (every event costs the stream
-    # about 6 us, so the launches around it are timed after the region, not inside it).
+    # ---- timed region: exactly `steps` steps between barriers.  The library brackets the INT64 gather launch and the
+    # BINARY launch of every step with two HIP events each, which the launches themselves record on the stream they
+    # run on (an event recorded between launches costs the stream about 6 us, so the other launches are timed after
+    # the region, not inside it).
     phase = (C.c_float * 3)()
     ncalls = C.c_int()
-    pq.check(pq.lib.pqd_phase_ms_mean(phase, C.byref(ncalls)))  # start a new series
+    for series in (0, 1):
+        pq.check(pq.lib.pqd_set_phase_series(series))
+        pq.check(pq.lib.pqd_phase_ms_mean(phase, C.byref(ncalls)))  # start a new series
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        c = cols[0]
-        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 4, stream)
-        c = cols[1]
+        decode_fixed(cols[0])
+        pq.check(pq.lib.pqd_set_phase_series(0))
         pq.check(pq.lib.pqd_set_phase_timing(2))
-        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 8, stream)
+        decode_fixed(cols[1])
+        pq.check(pq.lib.pqd_set_phase_series(1))
+        pq.check(pq.lib.pqd_set_phase_timing(2))
+        decode_binary()
         pq.check(pq.lib.pqd_set_phase_timing(0))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -400,18 +490,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
+    pq.check(pq.lib.pqd_set_phase_series(0))
+    pq.check(pq.lib.pqd_set_phase_timing(0))
     pq.check(pq.lib.pqd_phase_ms_mean(phase, C.byref(ncalls)))
-    gather_ms = phase[1]
-    # the other launches of an INT64 call, for the record: the same steps again with all four events
+    gather_ms, gather_calls = phase[1], ncalls.value
+    pq.check(pq.lib.pqd_set_phase_series(1))
+    pq.check(pq.lib.pqd_set_phase_timing(0))
+    pq.check(pq.lib.pqd_phase_ms_mean(phase, C.byref(ncalls)))
+    binary_ms, binary_calls = phase[1], ncalls.value
+    pq.check(pq.lib.pqd_set_phase_series(0))
+    # for the record, after the region: every column's call between two events, and the three launches of an INT64 call
+    per_col = [0.0, 0.0, 0.0]
+    ea, eb = Event(), Event()
+    for k in range(5):
+        for i, fn in enumerate((lambda: decode_fixed(cols[0]), lambda: decode_fixed(cols[1]), decode_binary)):
+            ea.record(stream)
+            fn()
+            eb.record(stream)
+            eb.sync()
+            per_col[i] += eb.ms_since(ea) / 5
     phase2 = (C.c_float * 3)()
     ncalls2 = C.c_int()
     for k in range(5):
-        c = cols[0]
-        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 4, stream)
-        c = cols[1]
+        decode_fixed(cols[0])
         pq.check(pq.lib.pqd_set_phase_timing(1))
-        pq.decode_pages_dev(c["descs"].data_ptr(), c["res"].data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 8, stream)
+        decode_fixed(cols[1])
         pq.check(pq.lib.pqd_set_phase_timing(0))
+        decode_binary()
     pq.check(pq.lib.pqd_phase_ms_mean(phase2, C.byref(ncalls2)))
     plan_ms, rest_ms = phase2[0], phase2[2]
 
@@ -435,82 +540,39 @@ def main():
                 b.sync()
                 total += b.ms_since(a)
             return total / iters
-        # BINARY column of configs[1]: the reference hands out zero-copy views into the dictionary page
-        # (PlainValuesDictionary.java:96-104), so the device work is the id decode (readValueDictionaryId)
+        # the BINARY column as the reference hands it out: zero-copy views into the dictionary page
+        # (PlainValuesDictionary.java:96-104), i.e. the id decode alone (readValueDictionaryId)
         c = cols[0]
-        id_descs, id_res = make_descs(c["blob"], c["page_len"], c["dictionary"], c["out"], 4, device,
+        id_descs, id_res = make_descs(binary["blob"], binary["page_len"], c["dictionary"], c["out"], 4, device,
                                       encoding=pq.ENC_RLE, flags=pq.F_WIDTH_PREFIX)
         ms = timed(lambda: pq.decode_pages_dev(id_descs.data_ptr(), id_res.data_ptr(), args.pages, pq.ENC_RLE, 4, stream))
-        ok = bool(torch.equal(c["out"].view(torch.int32), c["ids"]))
+        ok = bool(torch.equal(c["out"].view(torch.int32), binary["ids"]))
         extras["binary_column_as_dictionary_ids"] = {"ms": round(ms, 4), "values_per_s": round(args.pages * PAGE_VALUES / ms * 1e3, 1),
                                                      "verified": ok}
-
-        # ... and the same column materialised: offsets[n+1] + value bytes per page.  Dictionary entries of
-        # 4..12 bytes (a 768 KiB dictionary page); ids -> 8-byte views (the INT64 gather with the
+        # ... and materialised in two steps, as before the one-pass kernel: ids -> 8-byte views (the INT64 gather with the
         # dictionary's views as entries) -> k_binary_pages
-        rng = np.random.default_rng(77)
-        lens = rng.integers(4, 13, DICT_ENTRIES)
-        body = rng.integers(0, 256, int(lens.sum()), dtype=np.uint8)
-        page = np.zeros(int(lens.sum()) + 4 * DICT_ENTRIES, np.uint8)
-        starts = np.cumsum(lens + 4) - lens
-        for k in range(4):
-            page[starts - 4 + k] = (lens >> (8 * k)) & 0xFF
-        dst = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(body.size)
-        page[dst] = body
-        handle = C.c_void_p()
-        pq.check(pq.lib.pqd_dict_create(pq.TYPE_BYTE_ARRAY, 0, page.ctypes.data_as(C.c_void_p), page.size, DICT_ENTRIES,
-                                        C.byref(handle)))
-        info = pq.DictInfo()
-        pq.check(pq.lib.pqd_dict_get(handle, C.byref(info)))
         c = cols[1]
         views_out = c["out"]  # 8 bytes per value
-        v_pages = [dict(data=c["blob"].data_ptr() + i * c["page_len"], out=views_out.data_ptr() + i * PAGE_VALUES * 8,
-                        dict=info.entries, data_len=c["page_len"], num_values=PAGE_VALUES, dict_len=DICT_ENTRIES,
-                        encoding=pq.ENC_RLE_DICTIONARY, elem_size=8) for i in range(args.pages)]
-        v_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(v_pages))).to(device)
+        for i, pg in enumerate(binary["pages"]):
+            pg["out"] = views_out.data_ptr() + i * PAGE_VALUES * 8
+            binary["bd"][i].views = views_out.data_ptr() + i * PAGE_VALUES * 8
+        v_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(binary["pages"]))).to(device)
+        b_descs = torch.from_numpy(np.frombuffer(bytes(binary["bd"]), np.uint8).copy()).to(device)
         v_res = torch.zeros(args.pages * 16, dtype=torch.uint8, device=device)
-        cap = PAGE_VALUES * 12
-        b_offsets = torch.zeros((args.pages, PAGE_VALUES + 1), dtype=torch.int32, device=device)
-        b_bytes = torch.zeros((args.pages, cap), dtype=torch.uint8, device=device)
-        bd = (pq.BinaryPageDesc * args.pages)()
-        for i in range(args.pages):
-            bd[i].views = views_out.data_ptr() + i * PAGE_VALUES * 8
-            bd[i].dict_bytes = info.bytes
-            bd[i].offsets = b_offsets.data_ptr() + i * (PAGE_VALUES + 1) * 4
-            bd[i].bytes = b_bytes.data_ptr() + i * cap
-            bd[i].num_values = PAGE_VALUES
-            bd[i].dict_bytes_len = info.bytes_len
-            bd[i].bytes_capacity = cap
-        b_descs = torch.from_numpy(np.frombuffer(bytes(bd), np.uint8).copy()).to(device)
-        b_res = torch.zeros(args.pages * 16, dtype=torch.uint8, device=device)
-        ms_views = timed(lambda: pq.decode_pages_dev(v_descs.data_ptr(), v_res.data_ptr(), args.pages,
-                                                     pq.ENC_RLE_DICTIONARY, 8, stream))
-        ms_bytes = timed(lambda: pq.check(pq.lib.pqd_binary_materialize_dev(b_descs.data_ptr(), b_res.data_ptr(),
-                                                                            args.pages, stream)))
-        st_b, wr_b, nb_b = pq.results_from_numpy(b_res.cpu().numpy())
-        ok = bool((st_b == 0).all() and (wr_b == PAGE_VALUES).all())
-        chk = min(args.pages, 64)  # the first pages, value bytes rebuilt with torch
-        t_lens = torch.from_numpy(lens).to(device)
-        t_starts = torch.from_numpy(starts).to(device)
-        t_page = torch.from_numpy(page).to(device)
-        ids_chk = c["ids"][:chk].long()
-        l_chk = t_lens[ids_chk]
-        exp_off = torch.zeros((chk, PAGE_VALUES + 1), dtype=torch.int64, device=device)
-        exp_off[:, 1:] = torch.cumsum(l_chk, 1)
-        ok = ok and bool(torch.equal(exp_off.to(torch.int32), b_offsets[:chk]))
-        for i in range(chk):
-            src = torch.repeat_interleave(t_starts[ids_chk[i]] - exp_off[i, :-1], l_chk[i]) + \
-                torch.arange(int(exp_off[i, -1]), device=device)
-            ok = ok and bool(torch.equal(t_page[src], b_bytes[i, :int(exp_off[i, -1])]))
-        total_bytes = int(nb_b.astype(np.int64).sum())
-        alg = args.pages * c["page_len"] + args.pages * (PAGE_VALUES + 1) * 4 + total_bytes
+        one_pass = (binary["offsets"].clone(), binary["bytes"].clone())
+        binary["offsets"].zero_()
+        binary["bytes"].zero_()
+        ms_views = timed(lambda: pq.decode_pages_dev(v_descs.data_ptr(), v_res.data_ptr(), args.pages, pq.ENC_RLE_DICTIONARY, 8, stream))
+        ms_bytes = timed(lambda: pq.check(pq.lib.pqd_binary_materialize_dev(b_descs.data_ptr(), binary["bin_res"].data_ptr(), args.pages, stream)))
+        ok = bool(torch.equal(one_pass[0], binary["offsets"]) and torch.equal(one_pass[1], binary["bytes"]))
+        del one_pass
+        ms_one = timed(decode_binary)
+        alg_b = args.pages * binary["page_len"] + args.pages * (PAGE_VALUES + 1) * 4 + binary_bytes
         extras["binary_column_offsets_and_bytes"] = {
-            "ms_ids_to_views": round(ms_views, 4), "ms_views_to_bytes": round(ms_bytes, 4),
-            "values_per_s": round(args.pages * PAGE_VALUES / (ms_views + ms_bytes) * 1e3, 1),
-            "algorithmic_GBps": round(alg / (ms_views + ms_bytes) / 1e6, 1),
-            "mean_value_bytes": round(total_bytes / (args.pages * PAGE_VALUES), 2), "verified_pages": chk, "verified": ok}
-        pq.lib.pqd_dict_destroy(handle)
-        del b_offsets, b_bytes, t_page
+            "ms_one_pass_cold_input": round(ms_one, 4), "frac_of_hbm_peak": round(alg_b / ms_one / 1e6 / HBM_PEAK_GBS, 3),
+            "two_steps_ms_ids_to_views": round(ms_views, 4), "two_steps_ms_views_to_bytes": round(ms_bytes, 4),
+            "two_steps_frac_of_hbm_peak": round(alg_b / (ms_views + ms_bytes) / 1e6 / HBM_PEAK_GBS, 3),
+            "mean_value_bytes": round(binary_bytes / (args.pages * PAGE_VALUES), 2), "two_steps_equal_one_pass": ok}
 
         # the INT64 column again with sorted, run-heavy ids (a column sorted or clustered on its value): such pages
         # are decoded whole by the left-over launch, not through the chunk plan
@@ -527,6 +589,8 @@ def main():
             "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
             "page_bytes": r_len, "runs_per_page": 500, "verified": ok}
         del r_blob, r_ids
+        binary["offsets"] = binary["bytes"] = None
+        torch.cuda.empty_cache()
         extras["config5_shard"] = config5_shard(device, stream, timed, rank)
         if not args.no_config1:
             for c in cols:  # make room: the columns of the timed region are no longer needed
@@ -535,50 +599,68 @@ def main():
             extras["config1_hybrid_int32_pages_1M_values"] = config1_sweep(device, stream, timed)
 
     n_vals = args.pages * PAGE_VALUES
-    decoded_bytes_step = n_vals * (4 + 8)
     encoded_bytes_col = args.pages * cols[0]["page_len"]
-    # dominant kernel: the sliced gather of the INT64 column.  Algorithmic bytes per launch: the
-    # encoded pages once, the dictionary once, 8 bytes out per value
-    k64_ms = gather_ms
+    binary_decoded = n_vals * 4 + args.pages * 4 + binary_bytes  # offsets[n + 1] + bytes per page
+    decoded_bytes_step = n_vals * (4 + 8) + binary_decoded
+    # the kernels of a step, with their algorithmic bytes per launch: the encoded pages once, the dictionary once,
+    # the decoded bytes once
     k64_alg_bytes = encoded_bytes_col + n_vals * 8 + DICT_ENTRIES * 8
+    kbin_alg_bytes = encoded_bytes_col + binary_decoded + binary["page"].size
     ms_per_step = elapsed / args.steps * 1e3
     value = decoded_bytes_step * world / (elapsed / args.steps) / 1e9
 
     if rank == 0:
-        # HBM-side bytes per launch from the PMC passes (tools/pmc_traffic.sh): a number measured in
-        # another run, so it is reported only while the kernel sources are the ones it was measured on
-        traffic = None
+        # HBM-side bytes per launch from the PMC passes (tools/pmc_traffic.sh): numbers measured in
+        # another run, so they are reported only while the kernel sources are the ones they were measured on
+        traffic = traffic_bin = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("sources_sha256") == sources_digest():
                     traffic = rec.get("k_dict_pages_sliced_8_bytes_per_launch")
+                    traffic_bin = rec.get("k_binary_fused_bytes_per_launch")
             except Exception:
-                traffic = None
-        achieved = k64_alg_bytes / (k64_ms * 1e-3) / 1e9
+                traffic = traffic_bin = None
+        ach64 = k64_alg_bytes / (gather_ms * 1e-3) / 1e9
+        achb = kbin_alg_bytes / (binary_ms * 1e-3) / 1e9
+        step_alg = 3 * encoded_bytes_col + decoded_bytes_step
         line = {
             "metric": "device-resident decoded GB/s (RLE/bitpack+dict INT32 pages) at 1/2/4/8 GPUs",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "configs[1]: dictionary-encoded INT32 + INT64 columns, 65536-entry dictionaries "
-                                   "(id width 16), RLE/bit-packed hybrid ids (504-value runs, uniform random ids), "
-                                   f"{args.pages} pages x {PAGE_VALUES} values per column per GPU "
-                                   f"({n_vals / 1e6:.0f} M rows x 2 columns); the BINARY column is reported under extras",
+            "config": {"workload": "configs[1]: dictionary-encoded INT32 + INT64 + BINARY columns, 65536-entry dictionaries "
+                                   "(id width 16; BINARY entries of 4..12 bytes), RLE/bit-packed hybrid ids (504-value runs, "
+                                   f"uniform random ids), {args.pages} pages x {PAGE_VALUES} values per column per GPU "
+                                   f"({n_vals / 1e6:.0f} M rows x 3 columns)",
                        "pages_per_column": args.pages, "page_values": PAGE_VALUES, "dictionary_entries": DICT_ENTRIES,
                        "sharding": "one shard per GPU, no collective"},
-            "values_per_s": round(2 * n_vals * world / (elapsed / args.steps), 1),
-            "algorithmic_GBps": round((2 * encoded_bytes_col + decoded_bytes_step) * world / (elapsed / args.steps) / 1e9, 2),
+            "values_per_s": round(3 * n_vals * world / (elapsed / args.steps), 1),
+            "algorithmic_GBps": round(step_alg * world / (elapsed / args.steps) / 1e9, 2),
+            "whole_step_frac_of_hbm_peak": round(step_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "warmup_extra_steps_until_%d_ms" % int(args.warm_ms): extra_warm,
+            "ms_per_column_after_region": {"int32": round(per_col[0], 4), "int64": round(per_col[1], 4), "binary": round(per_col[2], 4),
+                                           "int32_plus_int64": round(per_col[0] + per_col[1], 4)},
+            "frac_of_hbm_peak_per_column": {
+                "int32": round((encoded_bytes_col + n_vals * 4) / per_col[0] / 1e6 / HBM_PEAK_GBS, 4),
+                "int64": round((encoded_bytes_col + n_vals * 8) / per_col[1] / 1e6 / HBM_PEAK_GBS, 4),
+                "binary": round((encoded_bytes_col + binary_decoded) / per_col[2] / 1e6 / HBM_PEAK_GBS, 4)},
             "verified_vs_gather": verified,
             "extras": extras,
-            "roofline": {"bound": "hbm", "kernel": "k_dict_pages_sliced<8> (INT64 dictionary pages)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": k64_alg_bytes, "avg_launch_ms": round(k64_ms, 4),
-                         "launches_timed": ncalls.value,
-                         "other_launches_ms": {"k_dict_slots + k_rle_plan + k_dict_planes": round(plan_ms, 4), "k_rle_pages (left-over pages)": round(rest_ms, 4),
-                                               "note": "timed after the region, five more steps"}},
+            "roofline": {"bound": "hbm", "kernel": "k_binary_fused (BINARY dictionary pages -> offsets + bytes): the longest kernel of the step",
+                         "achieved": round(achb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achb / HBM_PEAK_GBS, 4), "traffic": traffic_bin,
+                         "algorithmic_bytes_per_launch": kbin_alg_bytes, "avg_launch_ms": round(binary_ms, 4),
+                         "launches_timed": binary_calls},
+            "roofline_int64_gather": {"bound": "hbm", "kernel": "k_dict_pages_sliced<8> (INT64 dictionary pages)",
+                                      "achieved": round(ach64, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(ach64 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                      "algorithmic_bytes_per_launch": k64_alg_bytes, "avg_launch_ms": round(gather_ms, 4),
+                                      "launches_timed": gather_calls,
+                                      "other_launches_ms": {"k_dict_slots + k_rle_plan + k_dict_planes": round(plan_ms, 4),
+                                                            "k_rle_pages (left-over pages)": round(rest_ms, 4),
+                                                            "note": "timed after the region, five more steps"}},
         }
         # the reference's own CPU decoders need a JVM (scalar BytePacker; the Vector API plugin needs
         # avx512vbmi + avx512_vbmi2 as well): probed here, run only where they exist
@@ -597,6 +679,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, 99, 1)
             line["cpu_baseline_16_threads"] = cpu_baseline(min(args.cpu_seconds, 5.0), 99, 16)
         print(json.dumps(line), flush=True)
+    pq.lib.pqd_dict_destroy(binary["handle"])
     if distributed:
         dist.destroy_process_group()
 

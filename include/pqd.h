@@ -147,10 +147,14 @@ int pqd_event_elapsed_ms(void* start, void* stop, float* ms);
  * duration of each of the three launches in milliseconds and the number of calls averaged, and
  * starts a new series (disabling only pauses the recording).  enable = 2 times the gather launch alone,
  * with two events that the launch itself records at the kernel's start and end (ms[0] and ms[2] then
- * read 0): an event recorded between two launches costs the stream a few microseconds.  No counterpart
- * in the reference; off by default.
+ * read 0): an event recorded between two launches costs the stream a few microseconds.
+ * pqd_decode_binary_pages_dev is timed the same way (its one launch is ms[1]).  pqd_set_phase_series selects one
+ * of four independent series (0..3, 0 at first) that the calls after it record into and pqd_phase_ms_mean reads:
+ * a caller that alternates calls of different kinds keeps a series per kind.  No counterpart in the reference;
+ * off by default.
  */
 int pqd_set_phase_timing(int enable);
+int pqd_set_phase_series(int series);
 int pqd_phase_ms_mean(float ms[3], int* n_calls);
 
 /* ---- bulk bit-unpack: one bit-packed run --------------------------------------------------- */
@@ -304,6 +308,25 @@ typedef struct pqd_binary_page_desc {
 } pqd_binary_page_desc;
 int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                                void* stream);
+/*
+ * The two steps above in one: dictionary data pages of a BINARY column (BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY,
+ * INT96) -> offsets + bytes, without the views in between.  Replaces the read loop over
+ * DictionaryValuesReader.readBytes (DictionaryValuesReader.java:76-83: id = decoder.readInt();
+ * dictionary.decodeToBinary(id), PlainValuesDictionary.java:88-118) for whole pages.
+ * pages[i]: the data page as for pqd_decode_pages_dev (encoding PQD_ENC_RLE_DICTIONARY, elem_size 8, dict_len;
+ * `dict` and `out` are not used); bins[i]: where the page's values go (offsets, bytes, bytes_capacity) and
+ * dict_bytes / dict_bytes_len = pqd_dict_info.bytes / bytes_len of `dict` (views and num_values are not used).
+ * page_results[i] is what pqd_decode_pages_dev reports for the page's ids (status, values the read loop
+ * gets before it fails: PQD_PAST_END, PQD_DICT_OOB, ...); bin_results[i] what pqd_binary_materialize_dev reports
+ * for those values (values_written, bytes_consumed = bytes written; PQD_DECODE for a broken dictionary entry,
+ * PQD_BAD_ARG at the first value that does not fit).  Differences from the two steps: when a page stops at a
+ * broken entry or for lack of room, the id stream is not read further and page_results[i] is {PQD_OK, the
+ * values delivered, the stream bytes read so far}; after PQD_DICT_OOB bytes_consumed likewise counts the
+ * bytes read so far.  All pointers but `dict` are DEVICE pointers; asynchronous on `stream`.
+ */
+int pqd_decode_binary_pages_dev(const pqd_dict* dict, const pqd_page_desc* pages, const pqd_binary_page_desc* bins,
+                                pqd_page_result* page_results, pqd_page_result* bin_results, uint32_t n_pages,
+                                void* stream);
 /*
  * One BINARY dictionary data page, everything but the dictionary in HOST memory (what a Java
  * DictionaryValuesReader over a PlainBinaryDictionary calls from initFromPage): decodes the ids,

@@ -125,6 +125,7 @@ EXPORTS = {
     "pqd_event_record": ([C.c_void_p, C.c_void_p], C.c_int),
     "pqd_event_sync": ([C.c_void_p], C.c_int),
     "pqd_set_phase_timing": ([C.c_int], C.c_int),
+    "pqd_set_phase_series": ([C.c_int], C.c_int),
     "pqd_phase_ms_mean": ([C.POINTER(C.c_float), C.POINTER(C.c_int)], C.c_int),
     "pqd_event_elapsed_ms": ([C.c_void_p, C.c_void_p, C.POINTER(C.c_float)], C.c_int),
     "pqd_unpack_i32": ([C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t], C.c_int),
@@ -143,6 +144,7 @@ EXPORTS = {
     "pqd_dict_get": ([C.c_void_p, C.POINTER(DictInfo)], C.c_int),
     "pqd_dict_destroy": ([C.c_void_p], C.c_int),
     "pqd_binary_materialize_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
+    "pqd_decode_binary_pages_dev": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_def_levels_to_validity_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),
     "pqd_scatter_nulls_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p], C.c_int),
     "pqd_rep_levels_to_offsets_dev": ([C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p], C.c_int),

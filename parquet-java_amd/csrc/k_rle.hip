@@ -20,6 +20,7 @@
 #include "pqd_kernels.hpp"
 #include "pqd_expand.hpp"
 #include "pqd_rle_plan.hpp"
+#include "pqd_rle_scan.hpp"
 #include "pqd_whole_page.hpp"
 
 namespace pqd {
@@ -29,20 +30,6 @@ constexpr int WINDOW_BYTES = 24 * 1024;
 constexpr int WINDOW_SLACK = 48;  // >= 15 (alignment) + 20 (window over-read) rounded up
 constexpr int WINDOW_PIECES = (WINDOW_BYTES + WINDOW_SLACK) / 16;
 constexpr int MAX_SEGS = 512;
-constexpr uint32_t SEG_RLE = 0u, SEG_PACKED = 1u;
-
-struct RleState {
-  uint32_t pos;             // next unread byte of the stream (offset from desc.data)
-  uint32_t produced;        // values expanded before the current window
-  uint32_t window_values;   // values covered by the current segment table
-  uint32_t nseg;
-  uint32_t pending_groups;  // groups left of a bit-packed run whose header is already consumed
-  int32_t scan_status;      // first failure met by the header walk, PQD_OK if none
-  uint32_t scan_err_at;     // output index at which that failure happens
-  uint32_t oob_at;          // smallest output index with id >= dict_len (atomicMin), ~0u if none
-  uint32_t done;
-  int32_t window_base;      // stream offset of LDS byte 0 (may be slightly negative)
-};
 
 template <int ELEM, bool HAS_DICT>
 __device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint32_t lo, uint32_t hi,
@@ -100,138 +87,6 @@ __device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint3
         if (g0 + j >= lo && g0 + j < hi) o[j] = id[j];
     }
   }
-}
-
-// Header walk over the staged window; run by one lane.  Follows readNext() (:80-109).
-__device__ void rle_scan_window(RleState& st, const uint32_t* win, const uint8_t* data, uint32_t* seg_start,
-                                uint32_t* seg_src, uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values) {
-  uint32_t pos = st.pos;
-  const int32_t base = st.window_base;
-  const uint32_t wend = (uint32_t)(base + WINDOW_BYTES);  // stream offset one past the window
-  const uint32_t remaining = n_values - st.produced;
-  uint32_t vals = 0, nseg = 0, pending = st.pending_groups;
-  int32_t status = PQD_OK;
-  bool stop = false;
-  while (!stop && nseg < MAX_SEGS && vals < remaining) {
-    if (pending == 0) {
-      if (pos >= end) {  // :81 "Reading past RLE/BitPacking stream."
-        status = PQD_PAST_END;
-        break;
-      }
-      if (nseg > 0 && pos + 16 > wend && wend < end) break;  // header may straddle the window: restage
-      // BytesUtils.readUnsignedVarInt (parquet-common/.../BytesUtils.java:202-211)
-      uint32_t header = 0, shift = 0, p = pos, nb = 0;
-      for (;;) {
-        if (p >= end) {
-          status = PQD_EOF;
-          break;
-        }
-        // A header of more than five bytes is no writer's work, but the reference reads on until a
-        // byte without the continuation bit, its shifts wrapping at 32: such a header may leave the
-        // staged window, so from its sixth byte on it is read from memory.
-        uint32_t b = ++nb > 5 ? (uint32_t)data[p] : lds_byte(win, p - base);
-        ++p;
-        if (b & 0x80u) {
-          header |= (b & 0x7Fu) << (shift & 31u);
-          shift += 7;
-        } else {
-          header |= b << (shift & 31u);
-          break;
-        }
-      }
-      if (status) break;
-      if ((header & 1u) == 0) {
-        // RLE run: value on ceil(w/8) little-endian bytes, not masked to w (BytesUtils.java:124-142)
-        uint32_t count = header >> 1;
-        uint32_t nbytes = (w + 7) >> 3;
-        if (end - p < nbytes) {
-          status = PQD_EOF;
-          break;
-        }
-        uint32_t value = 0;
-        for (uint32_t i = 0; i < nbytes; ++i) value |= (nb > 5 ? (uint32_t)data[p + i] : lds_byte(win, p - base + i)) << (8 * i);
-        p += nbytes;
-        pos = p;
-        // a zero-count run leaves currentCount negative: the value repeats for the rest of the page
-        uint32_t take = (count == 0 || count > remaining - vals) ? remaining - vals : count;
-        seg_start[nseg] = vals;
-        seg_src[nseg] = value;
-        seg_kind[nseg] = SEG_RLE;
-        ++nseg;
-        vals += take;
-        continue;
-      }
-      uint32_t groups = header >> 1;
-      if (groups == 0 || groups > 0x0FFFFFFFu) {  // empty buffer indexed / negative array size
-        status = PQD_DECODE;
-        break;
-      }
-      pending = groups;
-      pos = p;
-    }
-    // bit-packed groups (8 values, w bytes each)
-    const uint32_t want_groups = (remaining - vals + 7) >> 3;
-    if (w == 0) {
-      uint32_t g = pending < want_groups ? pending : want_groups;
-      uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
-      seg_start[nseg] = vals;
-      seg_src[nseg] = 0;
-      seg_kind[nseg] = SEG_RLE;
-      ++nseg;
-      vals += take;
-      pending = 0;
-      continue;
-    }
-    const uint32_t avail = end > pos ? end - pos : 0u;      // real bytes left in the stream
-    const uint32_t with_data = (avail + w - 1) / w;         // groups holding at least one real byte
-    const uint32_t in_window = wend > pos ? (wend - pos) / w : 0u;
-    uint32_t g = pending;
-    if (g > want_groups) g = want_groups;
-    if (with_data == 0) {
-      // the stream ended inside the run: the rest of its buffer stays zero (:95-99)
-      uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
-      seg_start[nseg] = vals;
-      seg_src[nseg] = 0;
-      seg_kind[nseg] = SEG_RLE;
-      ++nseg;
-      vals += take;
-      pending = 0;
-      continue;
-    }
-    if (g > with_data) g = with_data;
-    if (g > in_window) g = in_window;
-    if (g == 0) {
-      stop = true;  // window exhausted: restage from pos
-      break;
-    }
-    uint32_t take = g * 8 > remaining - vals ? remaining - vals : g * 8;
-    seg_start[nseg] = vals;
-    seg_src[nseg] = (uint32_t)(pos - base);  // LDS byte offset of the first group
-    seg_kind[nseg] = SEG_PACKED;
-    ++nseg;
-    vals += take;
-    uint32_t bytes = g * w;
-    pos += bytes > avail ? avail : bytes;
-    pending -= g;
-  }
-  seg_start[nseg] = vals;
-  st.nseg = nseg;
-  st.window_values = vals;
-  st.pending_groups = pending;
-  if (status != PQD_OK) {
-    st.scan_status = status;
-    st.scan_err_at = st.produced + vals;
-    st.done = 1;
-  } else if (st.produced + vals >= n_values) {
-    // readNext consumed the whole payload of the last run when its header was read
-    if (pending > 0 && w > 0) {
-      uint64_t rest = (uint64_t)pending * w;
-      uint32_t avail = end > pos ? end - pos : 0u;
-      pos += rest > avail ? avail : (uint32_t)rest;
-    }
-    st.done = 1;
-  }
-  st.pos = pos;
 }
 
 // One page, decoded by the whole workgroup.
@@ -328,7 +183,7 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
     // ---- 2. header walk
     if (tid == 0) {
       st.window_base = wbase;
-      rle_scan_window(st, win, d.data, seg_start, seg_src, seg_kind, w, end, n_values);
+      rle_scan_window<WINDOW_BYTES, MAX_SEGS>(st, win, d.data, seg_start, seg_src, seg_kind, w, end, n_values);
     }
     __syncthreads();
     // ---- 3. expansion

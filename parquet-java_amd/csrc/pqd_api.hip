@@ -299,7 +299,12 @@ struct PhaseTimer {
   std::vector<hipEvent_t> events;  // 4 per call; the first `used` sets are recorded
   size_t used = 0;
 };
-thread_local PhaseTimer g_phase;
+// Several series side by side (pqd_set_phase_series): a benchmark that alternates calls of different kinds keeps one
+// series per kind.
+constexpr int PHASE_SERIES = 4;
+thread_local PhaseTimer g_phase_series[PHASE_SERIES];
+thread_local int g_phase_cur = 0;
+#define g_phase (g_phase_series[g_phase_cur])
 constexpr size_t PHASE_MAX_CALLS = 4096;
 
 int phase_mark(int i, hipStream_t s) {
@@ -514,6 +519,12 @@ int pqd_set_phase_timing(int enable) {
     return fail(PQD_BAD_ARG, "pqd_set_phase_timing: read the running series (pqd_phase_ms_mean) before changing the mode");
   t.enabled = enable != 0;  // pausing keeps what has been recorded
   if (enable != 0) t.gather_only = enable == 2;
+  return PQD_OK;
+}
+
+int pqd_set_phase_series(int series) {
+  if (series < 0 || series >= PHASE_SERIES) return fail(PQD_BAD_ARG, "pqd_set_phase_series: series 0..3");
+  g_phase_cur = series;
   return PQD_OK;
 }
 
@@ -868,11 +879,12 @@ int pqd_decode_page(const pqd_page_desc* desc, pqd_page_result* result) {
 
 int pqd_thread_release(void) {
   g_ctx.release();
-  PhaseTimer& t = g_phase;
-  for (auto e : t.events) (void)hipEventDestroy(e);
-  t.events.clear();
-  t.used = 0;
-  t.device = -1;
+  for (PhaseTimer& t : g_phase_series) {
+    for (auto e : t.events) (void)hipEventDestroy(e);
+    t.events.clear();
+    t.used = 0;
+    t.device = -1;
+  }
   return PQD_OK;
 }
 
@@ -907,6 +919,7 @@ int pqd_binary_dict_views(const uint8_t* page, size_t page_len, uint32_t n_entri
 struct pqd_dict {
   void* entries = nullptr;
   uint8_t* bytes = nullptr;
+  void* slots = nullptr;  // BINARY kinds: one 16-byte slot per entry for the one-pass decode (k_binary_fused.hip)
   uint32_t n_entries = 0, elem_size = 0, bytes_len = 0, physical_type = 0;
   int device = 0;
 };
@@ -962,10 +975,31 @@ int pqd_dict_create(int physical_type, int type_length, const uint8_t* page, siz
     d.bytes_len = (uint32_t)page_len;
     e = hipMalloc((void**)&d.bytes, page_len + 16);
     if (e == hipSuccess && page_len) e = hipMemcpy(d.bytes, page, page_len, hipMemcpyHostToDevice);
+    // slots: an entry of up to 12 bytes with its length behind it; a longer one as {offset, length, 0, 2^31};
+    // an entry that fails when it is read (PQD_VIEW_INVALID) as all ones
+    std::vector<uint32_t> slots((size_t)(n_entries ? n_entries : 1) * 4, 0u);
+    for (uint32_t i = 0; i < n_entries; ++i) {
+      uint32_t* sl = &slots[(size_t)i * 4];
+      const uint64_t v = views[i];
+      const uint32_t off = (uint32_t)v, len = (uint32_t)(v >> 32);
+      if (v == PQD_VIEW_INVALID) {
+        sl[0] = sl[1] = sl[2] = sl[3] = 0xFFFFFFFFu;
+      } else if (len <= 12u) {
+        memcpy(sl, page + off, len);
+        sl[3] = len;
+      } else {
+        sl[0] = off;
+        sl[1] = len;
+        sl[3] = 0x80000000u;
+      }
+    }
+    if (e == hipSuccess) e = hipMalloc(&d.slots, slots.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d.slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     (void)hipFree(d.entries);
     if (d.bytes) (void)hipFree(d.bytes);
+    if (d.slots) (void)hipFree(d.slots);
     return fail(PQD_HIP_ERROR, "dictionary upload", e);
   }
   *dict = new pqd_dict(d);
@@ -986,6 +1020,7 @@ int pqd_dict_get(const pqd_dict* dict, pqd_dict_info* info) {
 int pqd_dict_destroy(pqd_dict* dict) {
   if (!dict) return PQD_OK;
   hipError_t e1 = hipFree(dict->entries), e2 = dict->bytes ? hipFree(dict->bytes) : hipSuccess;
+  if (dict->slots) (void)hipFree(dict->slots);
   delete dict;
   if (e1 != hipSuccess) return fail(PQD_HIP_ERROR, "hipFree(dictionary entries)", e1);
   if (e2 != hipSuccess) return fail(PQD_HIP_ERROR, "hipFree(dictionary bytes)", e2);
@@ -997,6 +1032,23 @@ int pqd_binary_materialize_dev(const pqd_binary_page_desc* descs, pqd_page_resul
   if (n_pages == 0) return PQD_OK;
   if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
   PQD_HIP(pqd::launch_binary_pages(descs, results, n_pages, as_stream(stream)));
+  return PQD_OK;
+}
+
+int pqd_decode_binary_pages_dev(const pqd_dict* dict, const pqd_page_desc* pages, const pqd_binary_page_desc* bins,
+                                pqd_page_result* page_results, pqd_page_result* bin_results, uint32_t n_pages, void* stream) {
+  if (n_pages == 0) return PQD_OK;
+  if (!dict || !pages || !bins || !page_results || !bin_results) return fail(PQD_BAD_ARG, "null dictionary / descriptor / result array");
+  if (!dict->slots) return fail(PQD_BAD_ARG, "not a BINARY dictionary");
+  hipStream_t s = as_stream(stream);
+  int st;
+  if ((st = phase_mark(0, s))) return st;
+  if ((st = phase_mark(1, s))) return st;
+  hipEvent_t ev_start, ev_stop;
+  phase_gather_events(&ev_start, &ev_stop);
+  PQD_HIP(pqd::launch_binary_fused(pages, bins, dict->slots, dict->n_entries, page_results, bin_results, n_pages, s, ev_start, ev_stop));
+  if ((st = phase_mark(2, s))) return st;
+  if ((st = phase_mark(3, s))) return st;
   return PQD_OK;
 }
 

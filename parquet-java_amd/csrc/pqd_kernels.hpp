@@ -70,6 +70,9 @@ hipError_t launch_scatter_nulls(const pqd_scatter_desc* descs, pqd_page_result* 
                                 hipStream_t stream);
 hipError_t launch_rep_offsets(const pqd_offsets_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 // BINARY values gathered from their views into offsets + bytes, one workgroup per page
+hipError_t launch_binary_fused(const pqd_page_desc* pages, const pqd_binary_page_desc* bins, const void* slots, uint32_t n_slots,
+                               pqd_page_result* page_results, pqd_page_result* bin_results, uint32_t n_pages, hipStream_t stream,
+                               hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t launch_binary_pages(const pqd_binary_page_desc* descs, pqd_page_result* results, uint32_t n_pages,
                                hipStream_t stream);
 
