@@ -32,19 +32,35 @@ namespace pqd {
 constexpr int BF_THREADS = 256;
 constexpr int BF_VPL = 4;  // values per lane and tile
 constexpr uint32_t BF_TILE = BF_THREADS * BF_VPL;
-constexpr int BF_STREAM = 8 * 1024;  // stream bytes in LDS at a time
+#ifndef BF_STREAM_KIB
+#define BF_STREAM_KIB 8
+#endif
+#ifndef BF_DEFER  // 1: a tile's last window leaves at the top of the next tile (two windows in LDS); 0: at once
+#define BF_DEFER 1
+#endif
+#ifndef BF_PREFETCH  // 1: the next stream window is requested while this one's values are worked on
+#define BF_PREFETCH 1
+#endif
+#ifndef BF_WAVES
+#define BF_WAVES 4
+#endif
+constexpr int BF_STREAM = BF_STREAM_KIB * 1024;  // stream bytes in LDS at a time
 constexpr int BF_SLACK = 48;
 constexpr int BF_PIECES = (BF_STREAM + BF_SLACK) / 16;
 constexpr int BF_PRE = (BF_PIECES + BF_THREADS - 1) / BF_THREADS;  // pieces of the next window a lane holds in registers
-constexpr int BF_SEGS = 256;
+#ifndef BF_SEGS_N
+#define BF_SEGS_N 256
+#endif
+constexpr int BF_SEGS = BF_SEGS_N;
 constexpr uint32_t BF_WIN = 12 * 1024;  // output bytes staged per window: a tile of inline values
 constexpr uint32_t BF_NONE = 0xFFFFFFFFu;
 
 typedef uint32_t bf_u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
 // ORs `count` (1..16) bytes held in `v` into the zeroed window at byte position `dst`, eight bytes at a time.
-__device__ __forceinline__ void bf_or_bytes(unsigned long long* win, uint32_t dst, u32x4 v, uint32_t count) {
-  v = keep_leading_bytes(v, (long)count);
+// padded: the bytes of `v` behind `count` are zero already (an entry out of its slot).
+__device__ __forceinline__ void bf_or_bytes(unsigned long long* win, uint32_t dst, u32x4 v, uint32_t count, bool padded) {
+  if (!padded) v = keep_leading_bytes(v, (long)count);
   const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
   const uint32_t sh = (dst & 7u) * 8u, q = dst >> 3;
   const uint32_t nq = ((dst & 7u) + count + 7u) >> 3;  // quadwords touched: 1..3
@@ -56,14 +72,30 @@ __device__ __forceinline__ void bf_or_bytes(unsigned long long* win, uint32_t ds
   if (nq > 2u) atomicOr(&win[q + 2], (unsigned long long)p2);
 }
 
+// a + b, or 2^32 - 1 when that does not fit (lengths are summed in 32 bits; every sum that matters lies below
+// the capacity, which is below 2^31)
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
+  const uint32_t s = a + b;
+  return s < a ? 0xFFFFFFFFu : s;
+}
+__device__ __forceinline__ uint32_t wave_scan_inclusive_sat(uint32_t v) {
+  v = sat_add(v, dpp_or_zero<0x111, 0xF>(v));
+  v = sat_add(v, dpp_or_zero<0x112, 0xF>(v));
+  v = sat_add(v, dpp_or_zero<0x114, 0xF>(v));
+  v = sat_add(v, dpp_or_zero<0x118, 0xF>(v));
+  v = sat_add(v, dpp_or_zero<0x142, 0xA>(v));
+  v = sat_add(v, dpp_or_zero<0x143, 0xC>(v));
+  return v;
+}
+
 struct BfLds {
   u32x4 stream[BF_PIECES];
-  unsigned long long win[2][(BF_WIN + 32) / 8];  // two output windows: one is filled while the other leaves
+  unsigned long long win[1 + BF_DEFER][(BF_WIN + 32) / 8];  // two output windows: one is filled while the other leaves
   uint32_t seg_start[BF_SEGS + 1];
   uint32_t seg_src[BF_SEGS];
   uint32_t seg_kind[BF_SEGS];
-  uint64_t wave_total[BF_THREADS / 64];
-  uint64_t stop_bytes;
+  uint32_t wave_total[BF_THREADS / 64];
+  uint32_t stop_bytes;
   uint32_t stop, stop_kind, stop_flag;
   RleState st;
 };
@@ -81,30 +113,43 @@ constexpr uint32_t BF_STOP_OOB = 1, BF_STOP_VIEW = 2, BF_STOP_ROOM = 3;
 #define BF_T(k)
 #endif
 
-// A filled window -> memory, aligned 16-byte stores; the window is zero again afterwards.  gdst: where the window's
-// byte `s` goes (s = gdst & 15, so that piece i of the window is an aligned piece of memory).
-__device__ __forceinline__ void bf_flush(unsigned long long* win, PQD_GLOBAL uint8_t* gdst, uint32_t s, uint32_t wlen, uint32_t tid) {
-  const uint32_t pieces = (s + wlen + 15u) >> 4;
+// A filled window -> memory, aligned 16-byte stores; the window is zero again afterwards.  The window's LDS byte 0
+// stands for the 16-byte aligned address gdst - s; its bytes [s, s + wlen) are this window's, the bytes
+// [head_from, s) in front of them came over from the window before, the bytes [0, head_from) are not the page's at
+// all (head_from != 0: only while the page's first piece has not left).  The piece that holds the window's end, if
+// it is not full: written byte by byte when nothing follows (final); else handed back to the caller (the lane that
+// holds it gets carry_mine), who puts it in front of the next window, so that a page writes whole pieces all the
+// way but for its two ends.  Returns head_from of the next window.
+__device__ __forceinline__ uint32_t bf_flush(unsigned long long* win, PQD_GLOBAL uint8_t* gdst, uint32_t s, uint32_t wlen, uint32_t tid,
+                                             uint32_t head_from, bool final, u32x4& carry, bool& carry_mine) {
   const uint32_t wend = s + wlen;
+  const uint32_t pieces = (wend + 15u) >> 4;
+  carry_mine = false;
   for (uint32_t i = tid; i < pieces; i += BF_THREADS) {
     const u32x4 v = ((const u32x4*)win)[i];
     ((u32x4*)win)[i] = u32x4{0u, 0u, 0u, 0u};
     const uint32_t p0 = i * 16u;
-    if (p0 >= s && p0 + 16u <= wend) {
+    const bool whole_head = i != 0u || head_from == 0u, whole_tail = p0 + 16u <= wend;
+    if (whole_head && whole_tail) {
 #if BF_EXP != 3  // development: 3 = no byte stores
       PQD_STREAM_STORE((PQD_GLOBAL u32x4*)(gdst - s + p0), v);
 #endif
-    } else {  // the first and the last piece of a window: only the bytes that belong to it
+    } else if (!whole_tail && !final) {
+      carry = v;
+      carry_mine = true;
+    } else {  // the page's first and last piece: only the bytes that belong to it
+      const uint32_t from = i != 0u ? p0 : head_from;
 #pragma unroll 1
       for (uint32_t k = 0; k < 16u; ++k) {
         const uint32_t word = k < 8u ? (k < 4u ? v.x : v.y) : (k < 12u ? v.z : v.w);
-        if (p0 + k >= s && p0 + k < wend) gdst[(long)(p0 + k) - (long)s] = (uint8_t)(word >> ((k & 3u) * 8u));
+        if (p0 + k >= from && p0 + k < wend) gdst[(long)(p0 + k) - (long)s] = (uint8_t)(word >> ((k & 3u) * 8u));
       }
     }
   }
+  return wend < 16u && !final ? head_from : 0u;  // (the first piece stays in LDS only when it is also the unfinished last one)
 }
 
-__global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_binary_fused(
+__global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(BF_WAVES))) void k_binary_fused(
     const pqd_page_desc* __restrict__ pages, const pqd_binary_page_desc* __restrict__ bins, const u32x4* __restrict__ slots_,
     uint32_t n_slots, pqd_page_result* __restrict__ page_results, pqd_page_result* __restrict__ bin_results, uint32_t n_pages) {
   __shared__ BfLds L;
@@ -151,7 +196,7 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
   const PQD_GLOBAL uint8_t* dict_bytes = (const PQD_GLOBAL uint8_t*)b.dict_bytes;
   const uint64_t dict_bytes_len = b.dict_bytes_len;
   const PQD_GLOBAL uint8_t* always_there = (const PQD_GLOBAL uint8_t*)(page_results + page);  // 16 readable bytes
-  for (uint32_t i = tid; i < 2u * ((BF_WIN + 32) / 16); i += BF_THREADS) ((u32x4*)L.win)[i] = u32x4{0u, 0u, 0u, 0u};
+  for (uint32_t i = tid; i < (1u + BF_DEFER) * ((BF_WIN + 32) / 16); i += BF_THREADS) ((u32x4*)L.win)[i] = u32x4{0u, 0u, 0u, 0u};
   if (tid == 0) {
     L.stop = BF_NONE;
     L.stop_flag = 0;
@@ -175,6 +220,9 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
   // the output window that was filled last and has not left yet (wlen 0: none)
   uint32_t cur_buf = 0, pend_buf = 0, pend_s = 0, pend_len = 0;
   PQD_GLOBAL uint8_t* pend_dst = bytes;
+  uint32_t head_from = (uint32_t)((uintptr_t)bytes & 15u);  // see bf_flush: the page's bytes begin there in their first piece
+  u32x4 carry = {0u, 0u, 0u, 0u};
+  bool carry_mine = false;
 #if BF_EXP == 9
   uint32_t t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t t_last = __builtin_readcyclecounter();
@@ -182,16 +230,19 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
   // the first window of the stream, requested here and put into LDS at the top of the loop
   u32x4 pre[BF_PRE];
   const PQD_GLOBAL uint8_t* pre_base;
-  {
-    const PQD_GLOBAL uint8_t* gptr = (const PQD_GLOBAL uint8_t*)d.data + 1;
-    pre_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)gptr & ~(uintptr_t)15);
-#pragma unroll
-    for (int k = 0; k < BF_PRE; ++k) {
-      const PQD_GLOBAL uint8_t* p = pre_base + (size_t)(tid + k * BF_THREADS) * 16;
-      pre[k] = u32x4{0u, 0u, 0u, 0u};
-      if (tid + k * BF_THREADS < (uint32_t)BF_PIECES && p < gend) pre[k] = *(const PQD_GLOBAL u32x4*)p;
-    }
+#define BF_REQUEST_WINDOW(pos_)                                                                             \
+  {                                                                                                         \
+    const PQD_GLOBAL uint8_t* gptr_ = (const PQD_GLOBAL uint8_t*)d.data + (pos_);                           \
+    pre_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)gptr_ & ~(uintptr_t)15);                              \
+    _Pragma("unroll") for (int k = 0; k < BF_PRE; ++k) {                                                    \
+      const PQD_GLOBAL uint8_t* p_ = pre_base + (size_t)(tid + k * BF_THREADS) * 16;                        \
+      pre[k] = u32x4{0u, 0u, 0u, 0u};                                                                       \
+      if (tid + k * BF_THREADS < (uint32_t)BF_PIECES && p_ < gend) pre[k] = *(const PQD_GLOBAL u32x4*)p_;   \
+    }                                                                                                       \
   }
+#if BF_PREFETCH
+  BF_REQUEST_WINDOW(1u)
+#endif
   uint32_t pre_pos = 1;  // the stream position the requested window starts at
   __syncthreads();
 
@@ -199,6 +250,9 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     BF_T(9)
     // ---- the next window of the stream: out of the registers (bytes behind the stream's end are zero)
     const uint32_t cur = pre_pos;
+#if !BF_PREFETCH
+    BF_REQUEST_WINDOW(cur)
+#endif
     const int32_t wbase = (int32_t)cur - (int32_t)(((const PQD_GLOBAL uint8_t*)d.data + cur) - pre_base);
 #pragma unroll
     for (int k = 0; k < BF_PRE; ++k) {
@@ -207,9 +261,83 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     }
     __syncthreads();
     BF_T(0)
+    // The run headers.  What a writer makes of ids that do not repeat is one bit-packed run of 63 groups (504 values,
+    // header byte 0x7F) after the other: the lanes of wave 0 look at the places where the headers of such runs would be,
+    // all at once (behind what is left of a run that began in the window before), and the runs in front of the first
+    // place that holds something else, or whose run is not wholly in the window, in the stream and wanted, are in the
+    // table without a walk.  Then one lane walks on: ordinary runs (one header byte, wholly in the window and wanted)
+    // in a short loop, and whatever that loop does not take with the routine that knows every rule
+    // (rle_scan_window begins behind what is in the table and treats those runs exactly so).
+    uint32_t nseg0 = 0, vals0 = 0;
+    if (wave == 0 && w != 0u) {
+      const uint32_t pend = L.st.pending_groups;
+      const uint32_t remaining = n_values - L.st.produced;
+      const int64_t lim = (int64_t)wbase + BF_STREAM < (int64_t)end ? (int64_t)wbase + BF_STREAM : (int64_t)end;
+      const uint64_t pend_bytes = (uint64_t)pend * w;
+      const bool head_ok = pend == 0u || ((int64_t)(cur + pend_bytes) <= lim && (uint64_t)pend * 8u <= remaining);
+      if (head_ok) {
+        const uint32_t run_bytes = 1u + 63u * w;
+        const uint32_t base_vals = pend * 8u, seg0 = pend ? 1u : 0u;
+        const uint64_t p = cur + pend_bytes + (uint64_t)lane * run_bytes;
+        bool ok = (int64_t)(p + run_bytes) <= lim && (uint64_t)base_vals + (lane + 1u) * 504u <= remaining;
+        ok = ok && lds_byte(win_s, (uint32_t)((int64_t)p - wbase)) == 0x7Fu;
+        const uint64_t all = __builtin_amdgcn_ballot_w64(ok);
+        const uint32_t n_reg = all == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~all);
+        if (lane < n_reg) {
+          L.seg_start[seg0 + lane] = base_vals + lane * 504u;
+          L.seg_src[seg0 + lane] = (uint32_t)((int64_t)p + 1 - wbase);
+          L.seg_kind[seg0 + lane] = SEG_PACKED;
+        }
+        nseg0 = seg0 + n_reg;
+        vals0 = base_vals + n_reg * 504u;
+        if (lane == 0) {
+          if (pend) {
+            L.seg_start[0] = 0u;
+            L.seg_src[0] = (uint32_t)((int32_t)cur - wbase);
+            L.seg_kind[0] = SEG_PACKED;
+            L.st.pending_groups = 0u;
+          }
+          // ordinary runs, one after the other
+          uint32_t pos = cur + (uint32_t)pend_bytes + n_reg * run_bytes, nseg = nseg0, vals = vals0;
+          const uint32_t vb = (w + 7u) >> 3;
+          const uint32_t vmask = vb >= 4u ? ~0u : (1u << (8u * vb)) - 1u;
+          const int64_t wend = (int64_t)wbase + BF_STREAM;
+          while (nseg < (uint32_t)BF_SEGS - 1u && (int64_t)pos + 8 <= lim && vals < remaining) {
+            if (nseg > 0u && (int64_t)pos + 16 > wend && wend < (int64_t)end) break;  // (as the routine below: a new window first)
+            const uint32_t o = (uint32_t)((int32_t)pos - wbase), i = o >> 2, sh = (o & 3u) * 8u;
+            const uint32_t d0 = win_s[i], d1 = win_s[i + 1], d2 = win_s[i + 2];
+            const uint32_t head = funnel_shr(d0, d1, sh), next4 = funnel_shr(d1, d2, sh);
+            const uint32_t hb = head & 0xFFu;
+            if (hb & 0x80u) break;
+            const uint32_t cnt = hb >> 1;
+            if (cnt == 0u) break;
+            if (hb & 1u) {
+              const uint32_t len = 1u + cnt * w, nv = cnt * 8u;
+              if ((int64_t)pos + len > lim || nv > remaining - vals) break;
+              L.seg_start[nseg] = vals;
+              L.seg_src[nseg] = o + 1u;
+              L.seg_kind[nseg] = SEG_PACKED;
+              vals += nv;
+              pos += len;
+            } else {
+              if (cnt > remaining - vals) break;
+              L.seg_start[nseg] = vals;
+              L.seg_src[nseg] = ((head >> 8) | (next4 << 24)) & vmask;  // not masked to the width (BytesUtils.java:124-142)
+              L.seg_kind[nseg] = SEG_RLE;
+              vals += cnt;
+              pos += 1u + vb;
+            }
+            ++nseg;
+          }
+          nseg0 = nseg;
+          vals0 = vals;
+          L.st.pos = pos;
+        }
+      }
+    }
     if (tid == 0) {
       L.st.window_base = wbase;
-      rle_scan_window<BF_STREAM, BF_SEGS>(L.st, win_s, d.data, L.seg_start, L.seg_src, L.seg_kind, w, end, n_values);
+      rle_scan_window<BF_STREAM, BF_SEGS>(L.st, win_s, d.data, L.seg_start, L.seg_src, L.seg_kind, w, end, n_values, nseg0, vals0);
     }
     __syncthreads();
     BF_T(1)
@@ -219,67 +347,77 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     const bool last_window = L.st.done != 0;
     if (!last_window) {  // the window after this one: on its way while this one's values are worked on
       pre_pos = L.st.pos;
-      const PQD_GLOBAL uint8_t* gptr = (const PQD_GLOBAL uint8_t*)d.data + pre_pos;
-      pre_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)gptr & ~(uintptr_t)15);
-#pragma unroll
-      for (int k = 0; k < BF_PRE; ++k) {
-        const PQD_GLOBAL uint8_t* p = pre_base + (size_t)(tid + k * BF_THREADS) * 16;
-        pre[k] = u32x4{0u, 0u, 0u, 0u};
-        if (tid + k * BF_THREADS < (uint32_t)BF_PIECES && p < gend) pre[k] = *(const PQD_GLOBAL u32x4*)p;
-      }
+#if BF_PREFETCH
+      BF_REQUEST_WINDOW(pre_pos)
+#endif
     }
-    for (uint32_t t0 = 0; t0 < wv && !stopped; t0 += BF_TILE) {
-      const uint32_t l0 = t0 + tid * BF_VPL;  // the lane's first value, counted from the window's first
-      const uint32_t n_tile = wv - t0 < BF_TILE ? wv - t0 : BF_TILE;
-      // ---- ids
-      uint32_t id[BF_VPL] = {0u, 0u, 0u, 0u};
-      if (l0 < wv) {
-        uint32_t a = 0, e = nseg;  // invariant: seg_start[a] <= l0 < seg_start[e]
-        while (e - a > 1) {
-          const uint32_t m = (a + e) >> 1;
-          if (L.seg_start[m] <= l0)
-            a = m;
-          else
-            e = m;
-        }
-        const uint32_t s_begin = L.seg_start[a], s_end = L.seg_start[a + 1];
-        if (l0 + BF_VPL <= s_end) {
-          const uint32_t src = L.seg_src[a];
-          if (L.seg_kind[a] == SEG_PACKED) {
-            Window5 wnd = load_window(win_s, src * 8 + (l0 - s_begin) * w);
-            id[0] = wnd.d0 & mask;
-            wnd.drop(w);
-            id[1] = wnd.d0 & mask;
-            wnd.drop(w);
-            id[2] = wnd.d0 & mask;
-            wnd.drop(w);
-            id[3] = wnd.d0 & mask;
-          } else {
-            id[0] = id[1] = id[2] = id[3] = src;
+    // the ids of a tile's values (lx: the lane's first value, counted from the window's first)
+    auto tile_ids = [&](uint32_t lx, uint32_t (&id)[BF_VPL]) {
+      id[0] = id[1] = id[2] = id[3] = 0u;
+        if (lx < wv) {
+          uint32_t a = 0, e = nseg;  // invariant: seg_start[a] <= lx < seg_start[e]
+          while (e - a > 1) {
+            const uint32_t m = (a + e) >> 1;
+            if (L.seg_start[m] <= lx)
+              a = m;
+            else
+              e = m;
           }
-        } else {
-          uint32_t t = a;
-#pragma unroll
-          for (int j = 0; j < BF_VPL; ++j) {
-            const uint32_t l = l0 + j;
-            if (l >= wv) continue;
-            while (L.seg_start[t + 1] <= l) ++t;
-            const uint32_t src = L.seg_src[t];
-            if (L.seg_kind[t] == SEG_PACKED) {
-              const uint32_t bit = src * 8 + (l - L.seg_start[t]) * w;
-              id[j] = funnel_shr(win_s[bit >> 5], win_s[(bit >> 5) + 1], bit & 31u) & mask;
+          const uint32_t s_begin = L.seg_start[a], s_end = L.seg_start[a + 1];
+          if (lx + BF_VPL <= s_end) {
+            const uint32_t src = L.seg_src[a];
+            if (L.seg_kind[a] == SEG_PACKED && w <= 16u) {  // four ids in 64 bits behind any bit of a dword
+              const uint32_t bit = src * 8 + (lx - s_begin) * w, i = bit >> 5, sh = bit & 31u;
+              const uint32_t d0 = win_s[i], d1 = win_s[i + 1], d2 = win_s[i + 2];
+              const uint64_t bits = ((uint64_t)funnel_shr(d1, d2, sh) << 32) | funnel_shr(d0, d1, sh);
+              id[0] = (uint32_t)bits & mask;
+              id[1] = (uint32_t)(bits >> w) & mask;
+              id[2] = (uint32_t)(bits >> (2u * w)) & mask;
+              id[3] = (uint32_t)(bits >> (3u * w)) & mask;
+            } else if (L.seg_kind[a] == SEG_PACKED) {
+              Window5 wnd = load_window(win_s, src * 8 + (lx - s_begin) * w);
+              id[0] = wnd.d0 & mask;
+              wnd.drop(w);
+              id[1] = wnd.d0 & mask;
+              wnd.drop(w);
+              id[2] = wnd.d0 & mask;
+              wnd.drop(w);
+              id[3] = wnd.d0 & mask;
             } else {
-              id[j] = src;
+              id[0] = id[1] = id[2] = id[3] = src;
+            }
+          } else {
+            uint32_t t = a;
+#pragma unroll
+            for (int j = 0; j < BF_VPL; ++j) {
+              const uint32_t l = lx + j;
+              if (l >= wv) continue;
+              while (L.seg_start[t + 1] <= l) ++t;
+              const uint32_t src = L.seg_src[t];
+              if (L.seg_kind[t] == SEG_PACKED) {
+                const uint32_t bit = src * 8 + (l - L.seg_start[t]) * w;
+                id[j] = funnel_shr(win_s[bit >> 5], win_s[(bit >> 5) + 1], bit & 31u) & mask;
+              } else {
+                id[j] = src;
+              }
             }
           }
         }
+    };
+    uint32_t id_next[BF_VPL] = {0u, 0u, 0u, 0u};
+    bool have_next = false;
+    for (uint32_t t0 = 0; t0 < wv && !stopped; t0 += BF_TILE) {
+      const uint32_t l0 = t0 + tid * BF_VPL;  // the lane's first value, counted from the window's first
+      const uint32_t n_tile = wv - t0 < BF_TILE ? wv - t0 : BF_TILE;
+      // ---- ids: worked out while the tile before this one waited for its slots, but for a window's first tile
+      uint32_t id[BF_VPL];
+      if (have_next) {
+#pragma unroll
+        for (int j = 0; j < BF_VPL; ++j) id[j] = id_next[j];
+      } else {
+        tile_ids(l0, id);
       }
       BF_T(2)
-      // ---- the window of the tile before this one leaves (its stores are under way while the slots are fetched)
-      if (pend_len) {
-        bf_flush(L.win[pend_buf], pend_dst, pend_s, pend_len, tid);
-        pend_len = 0;
-      }
       BF_T(7)
       // ---- slots: one 16-byte gather per value, all four in flight together
       uint32_t len[BF_VPL], off[BF_VPL];
@@ -303,6 +441,17 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
           const bf_u32x4_a1 raw = *(const PQD_GLOBAL bf_u32x4_a1*)always_there;
           data[j] = u32x4{raw.x, raw.y, raw.z, 0u};
         }
+      }
+      // ---- while the slots are on their way: the next tile's ids, and the window of the tile before this one leaves
+      have_next = t0 + BF_TILE < wv;
+      if (have_next) tile_ids(l0 + BF_TILE, id_next);
+      if (pend_len) {  // (the window it filled last; the tile at hand fills the other one, whose first piece is free)
+        head_from = bf_flush(L.win[pend_buf], pend_dst, pend_s, pend_len, tid, head_from, false, carry, carry_mine);
+        if (carry_mine) ((u32x4*)L.win[cur_buf])[0] = carry;
+        pend_s = (pend_s + pend_len) & 15u;  // what is left in LDS: the bytes in front of the next window
+        pend_dst += pend_len;
+        pend_len = 0;
+        pend_buf = cur_buf;
       }
 #pragma unroll
       for (int j = 0; j < BF_VPL; ++j) {
@@ -339,36 +488,37 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
       }
       BF_T(3)
-      // ---- prefix sums of the lengths: lane, wave, workgroup
-      uint64_t lane_total = 0;
+      // ---- prefix sums of the lengths: lane, wave, workgroup (32 bits, saturating)
+      uint32_t lane_total = 0;
 #pragma unroll
-      for (int j = 0; j < BF_VPL; ++j) lane_total += len[j];
-      const uint64_t inc = wave_scan_inclusive(lane_total);
+      for (int j = 0; j < BF_VPL; ++j) lane_total = sat_add(lane_total, len[j]);
+      const uint32_t inc = wave_scan_inclusive_sat(lane_total);
       if (lane == 63) L.wave_total[wave] = inc;
       if ((oob_mask | bad_mask) != 0) L.stop_flag = 1u;  // (never cleared: such a value ends the page in this tile)
       __syncthreads();
-      uint64_t lane_base = inc - lane_total, tile_total = 0;
+      // (inc - lane_total is exact unless inc saturated, and then the lane lies behind the value that ends the page)
+      uint32_t lane_base = inc - lane_total, tile_total = 0;
 #pragma unroll
       for (int k = 0; k < BF_THREADS / 64; ++k) {
-        const uint64_t wt = L.wave_total[k];
-        if ((uint32_t)k < wave) lane_base += wt;
-        tile_total += wt;
+        const uint32_t wt = L.wave_total[k];
+        if ((uint32_t)k < wave) lane_base = sat_add(lane_base, wt);
+        tile_total = sat_add(tile_total, wt);
       }
       uint32_t pre_sum[BF_VPL];
       {
-        uint32_t acc = (uint32_t)lane_base;
+        uint32_t acc = lane_base;
 #pragma unroll
         for (int j = 0; j < BF_VPL; ++j) {
           pre_sum[j] = acc;
-          acc += len[j];
+          acc = sat_add(acc, len[j]);
         }
       }
-      uint32_t tile_bytes = (uint32_t)tile_total;
+      uint32_t tile_bytes = tile_total;
       uint32_t tile_values = n_tile;
       uint32_t stop = BF_NONE;  // tile-relative, BF_NONE if the whole tile is delivered
       if (L.stop_flag != 0u || (uint64_t)running + tile_total > cap) {  // (uniform) the page ends in this tile
         // the first value that is not delivered: an id beyond the dictionary, a broken entry, bytes beyond the capacity
-        uint64_t at = (uint64_t)running + lane_base;
+        uint64_t at = (uint64_t)running + lane_base;  // (a saturated base lies beyond the capacity as the true one does)
         uint32_t my_stop = BF_NONE;
 #pragma unroll
         for (int j = 0; j < BF_VPL; ++j) {
@@ -380,7 +530,7 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         __syncthreads();
         stop = L.stop;
         if (stop / BF_VPL == tid) {
-          uint64_t at2 = lane_base;
+          uint32_t at2 = lane_base;  // (exact: everything in front of the value that ends the page fits the capacity)
 #pragma unroll
           for (int j = 0; j < BF_VPL; ++j) {
             if ((uint32_t)j == stop % BF_VPL) {
@@ -391,7 +541,7 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
           }
         }
         __syncthreads();
-        tile_bytes = (uint32_t)L.stop_bytes;
+        tile_bytes = L.stop_bytes;
         stop_kind = L.stop_kind;
         tile_values = stop;
         stopped = true;
@@ -425,7 +575,7 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
           if (b1 <= wb || b0 >= wb + wlen) continue;
           if (((fast_mask >> j) & 1u) && b0 >= wb && b1 <= wb + wlen) {
 #if BF_EXP != 2  // development: 2 = no ORs
-            bf_or_bytes(win, s + (b0 - wb), data[j], len[j]);
+            bf_or_bytes(win, s + (b0 - wb), data[j], len[j], !((long_mask >> j) & 1u));
 #endif
           } else {
             slow_mask |= 1u << j;
@@ -446,7 +596,15 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             dj = me ? data[k] : dj;
           }
           const uint32_t lo = b0 > wb ? b0 : wb, hi = b0 + l < wb + wlen ? b0 + l : wb + wlen;
-          for (uint32_t p = lo; p < hi; ++p) {
+          uint32_t p = lo;
+          if (!inl) {  // a long entry: 16 bytes at a time while 16 bytes can be read from the dictionary page
+            for (; p < hi && (uint64_t)src0 + (p - b0) + 16u <= dict_bytes_len; p += 16u) {
+              const bf_u32x4_a1 raw = *(const PQD_GLOBAL bf_u32x4_a1*)(dict_bytes + (uint64_t)src0 + (p - b0));
+              bf_or_bytes(win, s + (p - wb), u32x4{raw.x, raw.y, raw.z, raw.w}, hi - p < 16u ? hi - p : 16u, false);
+            }
+            if (p > hi) p = hi;
+          }
+          for (; p < hi; ++p) {
             const uint32_t dst = s + (p - wb), k = p - b0;
             uint64_t byte;
             if (inl) {  // an inline entry that straddles a window edge: its bytes are in the registers
@@ -460,8 +618,14 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
         __syncthreads();
         BF_T(6)
-        if (wb + BF_WIN < tile_bytes) {  // not the tile's last window: it leaves at once
-          bf_flush(win, gdst, s, wlen, tid);
+        if (!BF_DEFER || wb + BF_WIN < tile_bytes) {  // not the tile's last window: it leaves at once
+          head_from = bf_flush(win, gdst, s, wlen, tid, head_from, false, carry, carry_mine);
+          __syncthreads();
+          if (carry_mine) ((u32x4*)win)[0] = carry;  // in front of the next window, which is filled in the same place
+          pend_buf = cur_buf;
+          pend_dst = gdst + wlen;
+          pend_s = (s + wlen) & 15u;
+          pend_len = 0;
           __syncthreads();
         } else {
           pend_buf = cur_buf;
@@ -478,7 +642,8 @@ __global__ __launch_bounds__(BF_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     if (last_window || stopped) break;
     __syncthreads();  // everybody is done with the stream window and the segment table
   }
-  if (pend_len) bf_flush(L.win[pend_buf], pend_dst, pend_s, pend_len, tid);
+  // what is still in LDS: the last window, or the bytes that came over from it into the next one's first piece
+  if (pend_len || pend_s > head_from) bf_flush(L.win[pend_buf], pend_dst, pend_s, pend_len, tid, head_from, true, carry, carry_mine);
 
   if (tid == 0) {
     // the id stream's own result, as the dictionary decode reports it

@@ -27,12 +27,13 @@ struct RleState {
 // Header walk over the staged window; run by one lane.  Follows readNext() (:80-109).
 template <int WINDOW_BYTES, int MAX_SEGS>
 __device__ void rle_scan_window(RleState& st, const uint32_t* win, const uint8_t* data, uint32_t* seg_start,
-                                uint32_t* seg_src, uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values) {
+                                uint32_t* seg_src, uint32_t* seg_kind, uint32_t w, uint32_t end, uint32_t n_values,
+                                uint32_t nseg0 = 0, uint32_t vals0 = 0) {  // nseg0 segments of vals0 values are in the table already
   uint32_t pos = st.pos;
   const int32_t base = st.window_base;
   const uint32_t wend = (uint32_t)(base + WINDOW_BYTES);  // stream offset one past the window
   const uint32_t remaining = n_values - st.produced;
-  uint32_t vals = 0, nseg = 0, pending = st.pending_groups;
+  uint32_t vals = vals0, nseg = nseg0, pending = st.pending_groups;
   int32_t status = PQD_OK;
   bool stop = false;
   while (!stop && nseg < MAX_SEGS && vals < remaining) {
