@@ -550,11 +550,16 @@ int pqd_chunk_set_value_counts_dev(pqd_page_desc* val_descs, const pqd_page_resu
  * the DEVICE and for many pages per call.  Codecs (numbered as parquet-format's CompressionCodec, which
  * CompressionCodecName.java:26-33 mirrors): SNAPPY = the raw Snappy format (SnappyDecompressor.java:27-35
  * -> org.xerial.snappy.Snappy.uncompress), LZ4_RAW = the LZ4 block format (Lz4RawDecompressor.java:29-49
- * -> io.airlift.compress.lz4.Lz4Decompressor), UNCOMPRESSED = a copy.  A page must produce exactly dst_len
- * bytes (the reference reads uncompressed_page_size bytes from the codec's stream): PQD_DECODE for a
- * malformed stream, one that would write past dst_len, or one that ends short of it ("could not
- * decompress page"); result.values_written = bytes produced, bytes_consumed = source bytes read.
- * desc.codec is the call's `codec` or PQD_CODEC_UNCOMPRESSED (stored parts of the same batch).
+ * -> io.airlift.compress.lz4.Lz4Decompressor), ZSTD = Zstandard frames without dictionaries, RFC 8878
+ * (ZstdDecompressorStream.java:30-60 -> zstd-jni's ZstdInputStreamNoFinalizer; the content checksum is not
+ * verified), GZIP = one or more gzip members, RFC 1952 around RFC 1951 deflate data (CodecFactory.java:165-217
+ * -> org.apache.hadoop.io.compress.GzipCodec, CompressionCodecName.java:28; every member's CRC-32 and length
+ * are verified), UNCOMPRESSED = a copy.  LZO, BROTLI and the Hadoop-framed LZ4 are not decoded here.  A page must
+ * produce exactly dst_len bytes (the reference reads uncompressed_page_size bytes from the codec's stream):
+ * PQD_DECODE for a malformed stream, one that would write past dst_len, or one that ends short of it ("could
+ * not decompress page"); result.values_written = bytes produced, bytes_consumed = source bytes read (GZIP: 0
+ * unless the page decodes).  desc.codec is the call's `codec` or PQD_CODEC_UNCOMPRESSED (stored parts of the
+ * same batch); a descriptor that names any other codec gets PQD_BAD_ARG.
  */
 enum pqd_codec {
   PQD_CODEC_UNCOMPRESSED = 0, PQD_CODEC_SNAPPY = 1, PQD_CODEC_GZIP = 2, PQD_CODEC_LZO = 3, PQD_CODEC_BROTLI = 4,
@@ -570,7 +575,7 @@ typedef struct pqd_decompress_desc {
 } pqd_decompress_desc;
 int pqd_decompress_pages_dev(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
                              void* stream);
-/* Whether pqd_decompress_pages_dev handles `codec` (SNAPPY, LZ4_RAW, UNCOMPRESSED). */
+/* Whether pqd_decompress_pages_dev handles `codec` (UNCOMPRESSED, SNAPPY, GZIP, LZ4_RAW, ZSTD). */
 int pqd_codec_supported(int codec);
 /*
  * All pages of a walked chunk: `pages` is the HOST table of pqd_chunk_walk, `chunk` the chunk's bytes on

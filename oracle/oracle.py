@@ -87,6 +87,7 @@ def _declare(L):
     L.orc_snappy_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
     L.orc_lz4_raw_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
     L.orc_zstd_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
+    L.orc_gzip_decompress.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, _szp, _szp]
     L.orc_xxh64.argtypes = [_u8p, C.c_size_t]
     L.orc_xxh64.restype = C.c_uint64
     L.orc_delta_length_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp, _szp]
@@ -357,10 +358,11 @@ def delta_byte_array(data, n, cap, prev=b""):
 
 # ---------------------------------------------------------------- page decompression
 def decompress(codec, data, size):
-    """(status, bytes produced, consumed) of a SNAPPY / LZ4_RAW / ZSTD page body that should hold `size` bytes."""
+    """(status, bytes produced, consumed) of a SNAPPY / LZ4_RAW / ZSTD / GZIP page body that should hold `size` bytes."""
     data = _u8(data)
     out = np.zeros(max(size, 1), np.uint8)
     made, used = C.c_size_t(0), C.c_size_t(0)
-    f = {"SNAPPY": lib().orc_snappy_decompress, "LZ4_RAW": lib().orc_lz4_raw_decompress, "ZSTD": lib().orc_zstd_decompress}[codec]
+    f = {"SNAPPY": lib().orc_snappy_decompress, "LZ4_RAW": lib().orc_lz4_raw_decompress, "ZSTD": lib().orc_zstd_decompress,
+         "GZIP": lib().orc_gzip_decompress}[codec]
     st = f(_p(data, _u8p), data.size, _p(out, _u8p), size, C.byref(made), C.byref(used))
     return st, out[:made.value], used.value

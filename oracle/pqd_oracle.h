@@ -121,6 +121,9 @@ int orc_lz4_raw_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_
 /* Zstandard frames (pqd_oracle_zstd.c, RFC 8878; no dictionaries) and the XXH64 of the content checksum */
 int orc_zstd_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced, size_t* consumed);
 uint64_t orc_xxh64(const uint8_t* p, size_t n);
+/* GZIP members (pqd_oracle_gzip.c, RFC 1952 / RFC 1951) and the CRC-32 of their trailers */
+int orc_gzip_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t* produced, size_t* consumed);
+uint32_t orc_crc32(uint32_t crc, const uint8_t* p, size_t n);
 
 /* ---- BytesUtils helpers (parquet-common BytesUtils.java:202-269), exposed for tests */
 int orc_read_uvarint32(const uint8_t* in, size_t len, size_t* pos, uint32_t* v);

@@ -16,7 +16,7 @@ import ctypes as _C
 import numpy as _np
 
 from . import _native
-from ._native import (BAD_ARG, CODEC_LZ4_RAW, CODEC_SNAPPY, CODEC_UNCOMPRESSED, CODEC_ZSTD, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
+from ._native import (BAD_ARG, CODEC_GZIP, CODEC_LZ4_RAW, CODEC_SNAPPY, CODEC_UNCOMPRESSED, CODEC_ZSTD, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
                       ENC_DELTA_BINARY_PACKED, ENC_DELTA_BYTE_ARRAY, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
                       HIP_ERROR, NO_DEVICE, OK, PAGE_DATA, PAGE_DATA_V2, PAGE_DICTIONARY, PAGE_INDEX, PAST_END, TYPE_BOOLEAN, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
@@ -727,7 +727,7 @@ class BytesDecompressor:
     """CodecFactory.BytesDecompressor (parquet-hadoop/.../hadoop/CodecFactory.java:165-217) for the codecs
     the device handles: ``decompress(bytes, decompressedSize)`` returns exactly ``decompressedSize``
     bytes or raises IOError, which ColumnChunkPageReadStore turns into "could not decompress page"."""
-    _codecs = {"UNCOMPRESSED": CODEC_UNCOMPRESSED, "SNAPPY": CODEC_SNAPPY, "LZ4_RAW": CODEC_LZ4_RAW, "ZSTD": CODEC_ZSTD}
+    _codecs = {"UNCOMPRESSED": CODEC_UNCOMPRESSED, "SNAPPY": CODEC_SNAPPY, "LZ4_RAW": CODEC_LZ4_RAW, "ZSTD": CODEC_ZSTD, "GZIP": CODEC_GZIP}
 
     def __init__(self, codecName):
         if codecName not in self._codecs or not lib.pqd_codec_supported(self._codecs[codecName]):

@@ -368,8 +368,8 @@ static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
                                    hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  if (codec == PQD_CODEC_ZSTD) {
-    hipError_t ez = launch_zstd_pages(descs, results, n_pages, stream);
+  if (codec == PQD_CODEC_ZSTD || codec == PQD_CODEC_GZIP) {
+    hipError_t ez = codec == PQD_CODEC_ZSTD ? launch_zstd_pages(descs, results, n_pages, stream) : launch_gzip_pages(descs, results, n_pages, stream);
     if (ez != hipSuccess) return ez;
     hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
     return hipGetLastError();

@@ -1136,7 +1136,8 @@ int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t
 }
 
 int pqd_codec_supported(int codec) {
-  return codec == PQD_CODEC_UNCOMPRESSED || codec == PQD_CODEC_SNAPPY || codec == PQD_CODEC_LZ4_RAW || codec == PQD_CODEC_ZSTD;
+  return codec == PQD_CODEC_UNCOMPRESSED || codec == PQD_CODEC_SNAPPY || codec == PQD_CODEC_GZIP || codec == PQD_CODEC_LZ4_RAW ||
+         codec == PQD_CODEC_ZSTD;
 }
 
 int pqd_decompress_pages_dev(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,

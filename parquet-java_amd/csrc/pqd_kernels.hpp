@@ -54,6 +54,7 @@ constexpr uint32_t DELTA_BYTES_WORK_HEADER = 64;
 hipError_t launch_delta_length_blocks(const pqd_delta_bytes_desc* descs, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_delta_bytes(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 // SNAPPY / LZ4_RAW / ZSTD pages (one wave each) and stored parts (desc.codec PQD_CODEC_UNCOMPRESSED)
+hipError_t launch_gzip_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
                                    hipStream_t stream);

@@ -17,7 +17,7 @@ import pagefile as pf
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "java_chunks.json")) as _f:
     JAVA = json.load(_f)["fixtures"]
-ARROW = pf.load_fixtures()
+ARROW = pf.load_fixtures() + pf.load_fixtures("pyarrow_gzip_chunks.json")
 ENC_NUM = {v: k for k, v in pf.ENCODINGS.items()}
 
 
@@ -97,7 +97,7 @@ def test_walk_failures():
 
 # ------------------------------------------------------------------------------- whole chunks on the device
 PHYS = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
-CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "LZ4": 7, "ZSTD": 6}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
+CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "LZ4": 7, "ZSTD": 6, "GZIP": 2}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
 WHOLE = [fx for fx in ARROW if fx["codec"] in CODECS and fx["max_rep"] == 0 and
          fx["physical_type"] in ("INT32", "INT64", "FLOAT", "DOUBLE", "BOOLEAN", "FIXED_LEN_BYTE_ARRAY") and
          not ({"DELTA_LENGTH_BYTE_ARRAY", "DELTA_BYTE_ARRAY"} & set(fx["encodings"]))]

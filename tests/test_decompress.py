@@ -1,8 +1,9 @@
-"""Page decompression (SNAPPY, LZ4_RAW, ZSTD).  The algorithms live in third-party libraries the reference
-calls (snappy-java 1.1.10.8, aircompressor 2.0.3, zstd-jni 1.5.7-13); the oracle restates the published formats
-(oracle/pqd_oracle_pages.c, pqd_oracle_zstd.c) and is pinned by byte strings and parquet pages compressed with
-the C libraries of the same formats through pyarrow (tests/golden/codec_vectors.json, pyarrow_chunks.json) and
-by hand-made streams that use every element type; the HIP kernels are checked against the oracle on all of
+"""Page decompression (SNAPPY, LZ4_RAW, ZSTD, GZIP).  The algorithms live in third-party libraries the reference
+calls (snappy-java 1.1.10.8, aircompressor 2.0.3, zstd-jni 1.5.7-13, Hadoop's GzipCodec over zlib); the oracle
+restates the published formats (oracle/pqd_oracle_pages.c, pqd_oracle_zstd.c, pqd_oracle_gzip.c) and is pinned by
+byte strings and parquet pages compressed with the C libraries of the same formats through pyarrow and Python's
+zlib module (tests/golden/codec_vectors.json, gzip_vectors.json, pyarrow_chunks.json, pyarrow_gzip_chunks.json)
+and by hand-made streams that use every element type; the HIP kernels are checked against the oracle on all of
 these, on streams compressed when the test runs (large inputs, several compression levels) and on damaged
 streams."""
 import base64
@@ -19,22 +20,33 @@ import pagefile as pf
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "codec_vectors.json")) as f:
     VECTORS = json.load(f)["vectors"]
+with open(os.path.join(HERE, "golden", "gzip_vectors.json")) as f:
+    VECTORS += json.load(f)["vectors"]
+GZIP_FORMS = ("_l1", "_l6", "_l9", "_fixed", "_stored", "_huffman_only", "_three_members", "_header_fields")
 INPUTS = dict(codec_inputs.inputs())
-CODEC_NUM = {"SNAPPY": 1, "LZ4_RAW": 7, "ZSTD": 6, "UNCOMPRESSED": 0}
-PAGE_CODEC = {"SNAPPY": "SNAPPY", "LZ4": "LZ4_RAW", "ZSTD": "ZSTD"}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
-PAGES = [fx for fx in pf.load_fixtures() if fx["codec"] in PAGE_CODEC]
-CODECS = ["SNAPPY", "LZ4_RAW", "ZSTD"]
+CODEC_NUM = {"SNAPPY": 1, "LZ4_RAW": 7, "ZSTD": 6, "UNCOMPRESSED": 0, "GZIP": 2}
+PAGE_CODEC = {"SNAPPY": "SNAPPY", "LZ4": "LZ4_RAW", "ZSTD": "ZSTD", "GZIP": "GZIP"}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
+PAGES = [fx for fx in pf.load_fixtures() + pf.load_fixtures("pyarrow_gzip_chunks.json") if fx["codec"] in PAGE_CODEC]
+CODECS = ["SNAPPY", "LZ4_RAW", "ZSTD", "GZIP"]
+
+
+def base_name(name):
+    """The input a vector's name refers to (ZSTD vectors are named input_l<level>, GZIP vectors input_<form>)."""
+    for form in GZIP_FORMS:
+        if name.endswith(form):
+            return name[:-len(form)]
+    return name
 
 
 def original(v):
     """The input a vector was made from (ZSTD vectors are named input_l<level>)."""
     name = v["name"]
-    return INPUTS[name.rsplit("_l", 1)[0] if v["codec"] == "ZSTD" else name]
+    return INPUTS[base_name(name) if v["codec"] in ("ZSTD", "GZIP") else name]
 
 
 class _Originals:
     def __getitem__(self, name):
-        return INPUTS[name] if name in INPUTS else INPUTS[name.rsplit("_l", 1)[0]]
+        return INPUTS[name] if name in INPUTS else INPUTS[base_name(name)]
 
 
 ORIGINALS = _Originals()
@@ -171,6 +183,113 @@ def handmade_lz4():
     return b"".join(parts), bytes(out)
 
 
+class BitWriter:
+    """Deflate's bit order: fields least significant bit first, Huffman codes most significant bit first."""
+
+    def __init__(self):
+        self.bits = []
+
+    def field(self, value, n):
+        self.bits += [(value >> k) & 1 for k in range(n)]
+
+    def code(self, value, n):
+        self.bits += [(value >> k) & 1 for k in range(n - 1, -1, -1)]
+
+    def align(self):
+        self.bits += [0] * (-len(self.bits) % 8)
+
+    def raw(self, data):
+        self.align()
+        for b in data:
+            self.field(b, 8)
+
+    def bytes(self):
+        self.align()
+        return bytes(sum(bit << k for k, bit in enumerate(self.bits[i:i + 8])) for i in range(0, len(self.bits), 8))
+
+
+def fixed_literal(w, sym):
+    """A literal / length symbol in the fixed code (RFC 1951 section 3.2.6)."""
+    if sym < 144:
+        w.code(0x30 + sym, 8)
+    elif sym < 256:
+        w.code(0x190 + sym - 144, 9)
+    elif sym < 280:
+        w.code(sym - 256, 7)
+    else:
+        w.code(0xC0 + sym - 280, 8)
+
+
+def gzip_member(deflate, raw, flg=0, extra=b""):
+    import zlib
+    return bytes([0x1F, 0x8B, 8, flg, 0, 0, 0, 0, 0, 255]) + extra + deflate + zlib.crc32(raw).to_bytes(4, "little") + \
+        (len(raw) & 0xFFFFFFFF).to_bytes(4, "little")
+
+
+def handmade_gzip():
+    """(stream, original): two members written bit by bit: an empty stored block, a fixed-code block with a match that
+    repeats one byte 258 times and one that overlaps itself, a stored block; then a member of one empty fixed block
+    and one whose dynamic code uses all three repeat codes and has a single distance code."""
+    w = BitWriter()
+    w.field(0, 1), w.field(0, 2), w.raw((0).to_bytes(2, "little") + (0xFFFF).to_bytes(2, "little"))  # stored, empty
+    w.field(0, 1), w.field(1, 2)
+    out = bytearray()
+    for ch in b"abc":
+        fixed_literal(w, ch)
+        out.append(ch)
+    fixed_literal(w, 257), w.code(2, 5)  # length 3, distance 3
+    out += out[-3:]
+    fixed_literal(w, 285), w.code(0, 5)  # length 258, distance 1
+    out += bytes([out[-1]]) * 258
+    fixed_literal(w, 265), w.field(1, 1), w.code(4, 5), w.field(1, 1)  # length 12, distance 6
+    for _ in range(12):
+        out.append(out[-6])
+    fixed_literal(w, 256)
+    w.field(1, 1), w.field(0, 2), w.raw((4).to_bytes(2, "little") + (0xFFFB).to_bytes(2, "little") + b"tail")
+    out += b"tail"
+    first = gzip_member(w.bytes(), bytes(out))
+    # second member: an empty fixed block, then a dynamic block.  Literal / length lengths: 'x' (120) and 'y' (121) 2 bits,
+    # end of block (256) 2 bits, length symbol 257 2 bits; one distance code of 1 bit (distance 1).
+    w = BitWriter()
+    w.field(0, 1), w.field(1, 2), fixed_literal(w, 256)
+    w.field(1, 1), w.field(2, 2)
+    w.field(258 - 257, 5), w.field(0, 5), w.field(19 - 4, 4)  # HLIT 258, HDIST 1, HCLEN 19
+    # code-length code: symbols 0 (2 bits), 1 (3), 2 (3), 16 (3), 17 (3), 18 (2) -> complete
+    cl = {0: 2, 1: 3, 2: 3, 16: 3, 17: 3, 18: 2}
+    for sym in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15):
+        w.field(cl.get(sym, 0), 3)
+    codes, code = {}, 0
+    for n in (2, 3):
+        for sym in sorted(cl):
+            if cl[sym] == n:
+                codes[sym] = (code, n)
+                code += 1
+        code <<= 1
+    def put(sym):  # noqa: E306
+        w.code(*codes[sym])
+    put(18), w.field(120 - 11, 7)           # 120 zeros
+    put(2), put(16), w.field(0, 2)          # 'x' = 2 bits; repeat it three times: 'y', 122, 123 (too many: fixed below)
+    # (the repeat above gave 121..123 two bits each; that is one code too many for a complete set, so take it back:
+    #  the stream is rebuilt with a repeat of exactly one further symbol, which code 16 cannot do: spell it out)
+    w2 = BitWriter()
+    w2.bits = w.bits[:-(3 + 2 + 3)]          # drop "2, 16, repeat"
+    w = w2
+    put(2), put(2)                          # 'x', 'y'
+    put(18), w.field(256 - 122 - 11, 7)     # zeros up to 255
+    put(2), put(2)                          # 256, 257
+    put(1)                                  # the distance code: 1 bit
+    raw2 = bytearray()
+    lit = {120: (0, 2), 121: (1, 2), 256: (2, 2), 257: (3, 2)}
+    for ch in b"xyyx":
+        w.code(*lit[ch])
+        raw2.append(ch)
+    w.code(*lit[257]), w.code(0, 1)          # length 3, distance 1
+    raw2 += bytes([raw2[-1]]) * 3
+    w.code(*lit[256])
+    second = gzip_member(w.bytes(), bytes(raw2))
+    return first + second, bytes(out) + bytes(raw2)
+
+
 # ------------------------------------------------------------------------------- oracle
 def test_codec_inputs_are_the_ones_that_were_compressed():
     for v in VECTORS:
@@ -246,10 +365,14 @@ def live_zstd_streams():
 def test_oracle_handmade_streams(orc):
     import pyarrow as pa
     for codec, (stream, raw) in (("SNAPPY", handmade_snappy()), ("SNAPPY", handmade_snappy_far_copies()),
-                                 ("LZ4_RAW", handmade_lz4()), ("ZSTD", handmade_zstd())):
+                                 ("LZ4_RAW", handmade_lz4()), ("ZSTD", handmade_zstd()), ("GZIP", handmade_gzip())):
         st, out, used = orc.decompress(codec, stream, len(raw))
         assert st == 0 and bytes(out) == raw and used == len(stream)
-        if codec != "ZSTD":  # (the library's one-shot call stops after the first frame)
+        if codec == "GZIP":  # (members one after the other: Python's gzip module reads on, the one-shot call does not)
+            import gzip
+            import io
+            assert gzip.GzipFile(fileobj=io.BytesIO(stream)).read() == raw
+        elif codec != "ZSTD":  # (the library's one-shot call stops after the first frame)
             assert pa.Codec(codec.lower()).decompress(stream, len(raw), asbytes=True) == raw  # the C library reads them alike
     for stream, raw in live_zstd_streams():
         st, out, used = orc.decompress("ZSTD", stream, len(raw))
@@ -274,6 +397,37 @@ def test_oracle_handmade_streams(orc):
     assert orc.decompress("LZ4_RAW", b"\x10a\x01", 5)[0] == D              # half an offset
     assert orc.decompress("LZ4_RAW", b"\x1fa\x01\x00\xff", 300)[0] == D    # length bytes run out
     assert orc.decompress("LZ4_RAW", b"\x10a\x01\x00", 5)[:2][1].tobytes() == b"aaaaa"
+    import zlib
+    good = gzip_member(zlib.compress(b"hello hello hello", 9)[2:-4], b"hello hello hello")
+    assert orc.decompress("GZIP", good, 17)[1].tobytes() == b"hello hello hello"
+    assert orc.decompress("GZIP", b"", 0)[0] == 0                           # nothing is read from a page of no bytes
+    assert orc.decompress("GZIP", b"", 1)[0] == D
+    assert orc.decompress("GZIP", good, 16)[0] == D and orc.decompress("GZIP", good, 18)[0] == D  # the page header disagrees
+    for at, byte in ((0, 0x1E), (1, 0x8A), (2, 7), (3, 0x20)):           # magic, method, a reserved flag
+        assert orc.decompress("GZIP", good[:at] + bytes([byte]) + good[at + 1:], 17)[0] == D
+    assert orc.decompress("GZIP", good[:-8] + bytes([good[-8] ^ 1]) + good[-7:], 17)[0] == D       # CRC-32
+    assert orc.decompress("GZIP", good[:-4] + bytes([good[-4] ^ 1]) + good[-3:], 17)[0] == D       # ISIZE
+    assert orc.decompress("GZIP", good[:-1], 17)[0] == D and orc.decompress("GZIP", good[:12], 17)[0] == D  # cut short
+    assert orc.decompress("GZIP", good + b"\x1f", 17)[0] == D                # something that is no member behind the last one
+    assert orc.decompress("GZIP", good + good, 34)[1].tobytes() == b"hello hello hello" * 2
+    w = BitWriter()
+    w.field(1, 1), w.field(3, 2)
+    assert orc.decompress("GZIP", gzip_member(w.bytes(), b""), 0)[0] == D    # block type 3
+    w = BitWriter()
+    w.field(1, 1), w.field(0, 2), w.raw((3).to_bytes(2, "little") + (0xFFFD).to_bytes(2, "little") + b"abc")
+    assert orc.decompress("GZIP", gzip_member(w.bytes(), b"abc"), 3)[0] == D  # LEN and NLEN disagree
+    w = BitWriter()
+    w.field(1, 1), w.field(1, 2), fixed_literal(w, ord("a")), fixed_literal(w, 257), w.code(1, 5), fixed_literal(w, 256)
+    assert orc.decompress("GZIP", gzip_member(w.bytes(), b"aaaa"), 4)[0] == D  # distance 2 behind one byte
+    w = BitWriter()
+    w.field(1, 1), w.field(1, 2), fixed_literal(w, ord("a")), fixed_literal(w, 257), w.code(30, 5), fixed_literal(w, 256)
+    assert orc.decompress("GZIP", gzip_member(w.bytes(), b"aaaa"), 4)[0] == D  # distance symbol 30
+    w = BitWriter()
+    w.field(1, 1), w.field(1, 2), fixed_literal(w, ord("a")), fixed_literal(w, 286), w.code(0, 5), fixed_literal(w, 256)
+    assert orc.decompress("GZIP", gzip_member(w.bytes(), b"aaaa"), 4)[0] == D  # length symbol 286
+    w = BitWriter()
+    w.field(1, 1), w.field(2, 2), w.field(30, 5), w.field(0, 5), w.field(0, 4)
+    assert orc.decompress("GZIP", gzip_member(w.bytes() + bytes(8), b""), 0)[0] == D  # 287 literal / length codes
     magic = (0xFD2FB528).to_bytes(4, "little")
     assert orc.decompress("ZSTD", b"", 0)[0] == 0                          # no frame at all: an empty page
     assert orc.decompress("ZSTD", magic + b"\x20\x00" + zstd_block(0, b"", last=True), 0)[0] == 0
@@ -345,7 +499,7 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
         if v["codec"] == codec_name:
             items.append((base64.b64decode(v["compressed"]), v["size"]))
             want.append(ORIGINALS[v["name"]])
-    stream, raw = {"SNAPPY": handmade_snappy, "LZ4_RAW": handmade_lz4, "ZSTD": handmade_zstd}[codec_name]()
+    stream, raw = {"SNAPPY": handmade_snappy, "LZ4_RAW": handmade_lz4, "ZSTD": handmade_zstd, "GZIP": handmade_gzip}[codec_name]()
     items.append((stream, len(raw)))
     want.append(raw)
     if codec_name == "ZSTD":
@@ -424,7 +578,7 @@ def test_gpu_damaged_streams(orc, codec_name):
     pq.init(0)
     rng = np.random.default_rng(123)
     base = [(base64.b64decode(v["compressed"]), v["size"]) for v in VECTORS
-            if v["codec"] == codec_name and v["name"].rsplit("_l", 1)[0] in ("short", "text", "ints", "mixed", "run_3", "timestamps")]
+            if v["codec"] == codec_name and base_name(v["name"]) in ("short", "text", "ints", "mixed", "run_3", "timestamps")]
     if codec_name == "ZSTD":
         magic = (0xFD2FB528).to_bytes(4, "little")
         base += [(s, len(r)) for s, r in live_zstd_streams()[:6]] + [(handmade_zstd()[0], len(handmade_zstd()[1]))]
@@ -458,14 +612,14 @@ def test_gpu_stored_parts_and_host_entry(orc):
     (st, data, used), = run_batch(pq, gh, torch, 0, [(b"abcdef", 4)])
     assert st == orc.DECODE and data == b"abcd"
     assert pq.lib.pqd_codec_supported(1) and pq.lib.pqd_codec_supported(7) and pq.lib.pqd_codec_supported(6)
-    assert not pq.lib.pqd_codec_supported(2)
+    assert pq.lib.pqd_codec_supported(2) and not pq.lib.pqd_codec_supported(3) and not pq.lib.pqd_codec_supported(4)
     # the host entry behind the BytesDecompressor mirror
     for name in CODECS:
         d = pq.BytesDecompressor(name)
         for v in VECTORS:
-            if v["codec"] == name and v["name"].rsplit("_l", 1)[0] in ("empty", "short", "text", "random"):
+            if v["codec"] == name and base_name(v["name"]) in ("empty", "short", "text", "random"):
                 assert d.decompress(base64.b64decode(v["compressed"]), v["size"]) == ORIGINALS[v["name"]]
         with pytest.raises(IOError):
             d.decompress(b"\x05\x10abcd", 5)
     with pytest.raises(pq.IllegalArgumentException):
-        pq.BytesDecompressor("GZIP")
+        pq.BytesDecompressor("BROTLI")
