@@ -68,7 +68,8 @@ enum pqd_encoding {
                                       -> one byte (0 / 1) per value (elem_size 1) or one int32 (elem_size 4);
                                       bytes_consumed = min(ceil(num_values / 8), data_len) */
   PQD_ENC_DELTA_LENGTH_BYTE_ARRAY = 8, /* pqd_delta_byte_array_dev only */
-  PQD_ENC_DELTA_BYTE_ARRAY = 9         /* pqd_delta_byte_array_dev only */
+  PQD_ENC_DELTA_BYTE_ARRAY = 9,        /* pqd_delta_byte_array_dev only */
+  PQD_ENC_PLAIN_BYTE_ARRAY = 10        /* pqd_delta_byte_array_dev only: [length: 4 bytes LE][bytes] ... */
 };
 
 /* pqd_page_desc.flags */
@@ -337,9 +338,11 @@ int pqd_decode_binary_pages_dev(const pqd_dict* dict, const pqd_page_desc* pages
 int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                            int32_t* offsets, uint8_t* bytes, uint32_t bytes_capacity, pqd_page_result* result);
 
-/* ---- DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY value pages ------------------------------------------ */
+/* ---- PLAIN BYTE_ARRAY / DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY value pages ------------------------- */
 /*
- * Replaces the read loops over DeltaLengthByteArrayValuesReader (parquet-column/.../values/
+ * Replaces the read loops over BinaryPlainValuesReader (parquet-column/.../values/plain/
+ * BinaryPlainValuesReader.java:36-74: every value is its length in four little-endian bytes and then its bytes;
+ * a value that cannot be read fails with "could not read bytes at offset"), DeltaLengthByteArrayValuesReader (parquet-column/.../values/
  * deltalengthbytearray/DeltaLengthByteArrayValuesReader.java:33-77: all lengths as one
  * DELTA_BINARY_PACKED block, then the values back to back; readBytes slices `length` bytes and fails
  * with "Failed to read N bytes" when the page ends first) and DeltaByteArrayReader (.../deltastrings/
@@ -352,7 +355,10 @@ int pqd_decode_binary_page(const pqd_dict* dict, const uint8_t* page, uint32_t p
  * offsets[values_written] = end of the last value delivered = result.reserved; result.bytes_consumed =
  * page bytes read (length blocks + value bytes).  With bytes == NULL a DELTA_LENGTH_BYTE_ARRAY page is
  * left where it is (the reference's zero-copy Binary views): value i is
- * data[bytes_consumed - reserved + offsets[i] ...].
+ * data[bytes_consumed - reserved + offsets[i] ...]; a PLAIN page likewise: value i is
+ * data[offsets[i] + 4 * (i + 1) ...].  PLAIN pages: PQD_DECODE at the first value whose length field or bytes do not
+ * lie inside the page or whose length is negative; bytes_consumed = the page bytes in front of the first value
+ * not delivered; `work` is not used (may be NULL); pages above 2^31-1 bytes are PQD_BAD_ARG.
  * Status: a length block that fails fails the page before its first value (both readers decode their
  * length blocks in initFromPage); PQD_DECODE at the first value whose length is negative, whose bytes
  * run past the page, whose prefix is longer than the value before it, or that has no length left in
@@ -374,7 +380,7 @@ typedef struct pqd_delta_bytes_desc {
   uint32_t data_len;
   uint32_t num_values;
   uint32_t bytes_capacity;
-  uint32_t encoding;           /* PQD_ENC_DELTA_LENGTH_BYTE_ARRAY or PQD_ENC_DELTA_BYTE_ARRAY        */
+  uint32_t encoding;           /* PQD_ENC_PLAIN_BYTE_ARRAY, _DELTA_LENGTH_BYTE_ARRAY or _DELTA_BYTE_ARRAY */
   uint32_t prev_count;
   uint32_t reserved;
 } pqd_delta_bytes_desc;
@@ -382,8 +388,8 @@ int pqd_delta_byte_array_dev(const pqd_delta_bytes_desc* descs, pqd_page_result*
 /*
  * One such page in HOST memory (what initFromPage + the read loop of the two readers see); `previous`
  * is the last value of the page before (DELTA_BYTE_ARRAY only, may be NULL / 0).  *bytes_needed (may
- * be NULL) receives the sum of all lengths in the page's length blocks: the capacity with which a
- * call that ended in PQD_BAD_ARG succeeds.  Thread-safe like the other host entry points.
+ * be NULL) receives the sum of all lengths in the page's length blocks (PLAIN: of the values that can be
+ * read): the capacity with which a call that ended in PQD_BAD_ARG succeeds.  Thread-safe like the other host entry points.
  */
 int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t page_len, uint32_t num_values,
                                      const uint8_t* previous, uint32_t previous_len, int32_t* offsets, uint8_t* bytes,
@@ -511,8 +517,11 @@ uint32_t pqd_crc32(uint32_t crc, const uint8_t* data, size_t len);
  *                 column's physical type; num_values = the page's value count incl. nulls (an upper
  *                 bound; pqd_chunk_set_value_counts_dev lowers it to the non-null count once the
  *                 definition levels are decoded); out = val_out + value_base[i] * elem_size;
- *                 dict / dict_len as given.  Encodings this library does not decode (the BYTE_ARRAY
- *                 ones) give encoding 0: such a descriptor is rejected by pqd_decode_pages_dev.
+ *                 dict / dict_len as given.  PLAIN pages of a BYTE_ARRAY column, DELTA_LENGTH_BYTE_ARRAY and
+ *                 DELTA_BYTE_ARRAY pages get encoding PQD_ENC_PLAIN_BYTE_ARRAY / _DELTA_LENGTH_BYTE_ARRAY /
+ *                 _DELTA_BYTE_ARRAY, elem_size 0 and no `out`: their values go through pqd_delta_byte_array_dev
+ *                 (a pqd_delta_bytes_desc takes data, data_len, num_values and encoding from this descriptor).
+ *                 An encoding the column's type cannot have gives encoding 0: pqd_decode_pages_dev rejects it.
  * results[i].status: PQD_OK, or PQD_EOF / PQD_DECODE when a level section runs past the page.
  */
 typedef struct pqd_column_meta {

@@ -91,6 +91,7 @@ def _declare(L):
     L.orc_xxh64.argtypes = [_u8p, C.c_size_t]
     L.orc_xxh64.restype = C.c_uint64
     L.orc_delta_length_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp, _szp]
+    L.orc_plain_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp, _szp]
     L.orc_delta_byte_array.argtypes = [_u8p, C.c_size_t, C.c_size_t, _u8p, C.c_size_t, _i32p, _u8p, C.c_size_t, _szp, _szp,
                                        _szp]
 
@@ -328,6 +329,20 @@ def rep_offsets(rep, deff, slot_def, row_def, rows_cap):
                                _p(row_valid, _u8p), C.byref(rows), C.byref(slots))
     k = min(rows.value, rows_cap)
     return st, offsets[:k + 1], row_valid[:k], rows.value, slots.value
+
+
+# ---------------------------------------------------------------- PLAIN BYTE_ARRAY
+def plain_byte_array(data, n, cap=None, in_place=False):
+    """(status, offsets[written + 1], bytes, consumed) of a PLAIN page of BYTE_ARRAY values; in_place: the bytes
+    are not copied (bytes comes back empty, the last offset still counts them)."""
+    data = _u8(data)
+    cap = data.size if cap is None else cap
+    offsets = np.zeros(n + 1, np.int32)
+    out = np.zeros(max(cap, 1), np.uint8)
+    wr, used, nb = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    st = lib().orc_plain_byte_array(_p(data, _u8p), data.size, n, _p(offsets, _i32p), None if in_place else _p(out, _u8p), cap,
+                                    C.byref(wr), C.byref(used), C.byref(nb))
+    return st, offsets[:wr.value + 1], out[:0 if in_place else nb.value], used.value
 
 
 # ---------------------------------------------------------------- DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY

@@ -104,6 +104,9 @@ int orc_scatter_nulls(const uint8_t* values, size_t n_values, const uint8_t* val
 int orc_rep_offsets(const int32_t* rep, const int32_t* def, size_t n, int32_t slot_def, int32_t row_def, size_t rows_cap,
                     int32_t* offsets, uint8_t* row_valid, size_t* n_rows, size_t* n_slots);
 
+/* ---- PLAIN BYTE_ARRAY (BinaryPlainValuesReader.java:36-74) -> offsets + bytes; bytes may be NULL */
+int orc_plain_byte_array(const uint8_t* in, size_t in_len, size_t n, int32_t* offsets, uint8_t* bytes, size_t cap,
+                         size_t* written, size_t* consumed, size_t* bytes_written);
 /* ---- DELTA_LENGTH_BYTE_ARRAY (DeltaLengthByteArrayValuesReader.java:44-58) and DELTA_BYTE_ARRAY
  * (DeltaByteArrayReader.java:50-95) -> offsets + bytes; bytes may be NULL for the first (values stay in the page) */
 int orc_delta_length_byte_array(const uint8_t* in, size_t in_len, size_t n, int32_t* offsets, uint8_t* bytes,

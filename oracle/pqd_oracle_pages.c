@@ -142,6 +142,47 @@ static int read_length_block(const uint8_t* in, size_t in_len, size_t cap, int32
   return ORC_OK;
 }
 
+/* BinaryPlainValuesReader.java:36-74 (parquet-column/.../values/plain/): initFromPage keeps everything that is
+ * available; readBytes reads the length (BytesUtils.readIntLittleEndian: four bytes, EOFException when fewer are
+ * left) and slices that many bytes (EOFException when the page ends first); either failure becomes
+ * ParquetDecodingException("could not read bytes at offset ...").  A negative length is reported as a decode
+ * error (the reference's streams disagree on it, as for the delta encodings).  offsets[i] = sum of the lengths in
+ * front of value i; bytes may be NULL (the values stay in the page: value i at in[offsets[i] + 4 * (i + 1)]).
+ * *consumed = the page bytes in front of the first value not delivered. */
+int orc_plain_byte_array(const uint8_t* in, size_t in_len, size_t n, int32_t* offsets, uint8_t* bytes, size_t cap,
+                         size_t* written, size_t* consumed, size_t* bytes_written) {
+  *written = *consumed = *bytes_written = 0;
+  offsets[0] = 0;
+  if (in_len > 0x7fffffffu) return ORC_BAD_ARG;
+  if (cap > 0x7fffffffu || !bytes) cap = 0x7fffffffu;
+  int st = ORC_OK;
+  size_t pos = 0, out = 0, i = 0;
+  for (; i < n; ++i) {
+    offsets[i] = (int32_t)out;
+    if (in_len - pos < 4) {
+      st = ORC_DECODE;
+      break;
+    }
+    const uint32_t raw = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+    if ((int32_t)raw < 0 || (size_t)raw > in_len - pos - 4) {
+      st = ORC_DECODE;
+      break;
+    }
+    if (out + raw > cap) {
+      st = ORC_BAD_ARG;
+      break;
+    }
+    if (bytes) memcpy(bytes + out, in + pos + 4, raw);
+    pos += 4 + (size_t)raw;
+    out += raw;
+  }
+  offsets[i] = (int32_t)out;
+  *written = i;
+  *consumed = pos;
+  *bytes_written = out;
+  return st;
+}
+
 /* DeltaLengthByteArrayValuesReader.java:44-58: initFromPage reads every length, the values follow back
  * to back; readBytes takes the next length and slices that many bytes ("Failed to read N bytes" when
  * the page ends first).  A length block with fewer lengths than the page has values fails the read

@@ -17,13 +17,13 @@ import numpy as _np
 
 from . import _native
 from ._native import (BAD_ARG, CODEC_GZIP, CODEC_LZ4_RAW, CODEC_SNAPPY, CODEC_UNCOMPRESSED, CODEC_ZSTD, DECODE, DICT_OOB, ENC_BIT_PACKED, ENC_BYTE_STREAM_SPLIT,  # noqa: F401
-                      ENC_DELTA_BINARY_PACKED, ENC_DELTA_BYTE_ARRAY, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
+                      ENC_DELTA_BINARY_PACKED, ENC_DELTA_BYTE_ARRAY, ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_PLAIN, ENC_PLAIN_BOOLEAN, ENC_PLAIN_BYTE_ARRAY, ENC_RLE, ENC_RLE_DICTIONARY, EOF, F_LENGTH_PREFIX, F_WIDTH_PREFIX,
                       HIP_ERROR, NO_DEVICE, OK, PAGE_DATA, PAGE_DATA_V2, PAGE_DICTIONARY, PAGE_INDEX, PAST_END, TYPE_BOOLEAN, TYPE_BYTE_ARRAY, TYPE_DOUBLE, TYPE_FIXED_LEN_BYTE_ARRAY, TYPE_FLOAT,
                       TYPE_INT32, TYPE_INT64, TYPE_INT96, VIEW_INVALID,
                       BinaryPageDesc, ChunkOutputs, ChunkPage, ColumnMeta, DecompressDesc, DeltaBytesDesc, DictInfo, OffsetsDesc, PageDesc, PageResult, PqdError, ScatterDesc, ValidityDesc, check, lib)
 
 __all__ = ["ParquetReadRouter", "Packer", "BytePacker", "BytePackerForLong", "ByteBufferInputStream", "ValuesReader", "RunLengthBitPackingHybridValuesReader",
-           "DictionaryValuesReader", "PlainBinaryDictionary", "BytesDecompressor", "DeltaBinaryPackingValuesReader", "DeltaLengthByteArrayValuesReader", "DeltaByteArrayReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
+           "DictionaryValuesReader", "PlainBinaryDictionary", "BytesDecompressor", "DeltaBinaryPackingValuesReader", "DeltaLengthByteArrayValuesReader", "DeltaByteArrayReader", "BinaryPlainValuesReader", "ByteStreamSplitValuesReader", "PlainValuesReader", "BooleanPlainValuesReader",
            "ByteBitPackingValuesReader", "ZeroIntegerValuesReader", "ParquetDecodingException", "EOFException",
            "IllegalArgumentException", "device_count", "init", "decode_pages_dev", "make_descs", "lib"]
 
@@ -568,7 +568,7 @@ class DeltaLengthByteArrayValuesReader(ValuesReader):
             if r.status != BAD_ARG or need.value <= cap:
                 break
             cap = need.value  # the lengths asked for more room than the first guess
-        if r.status != OK and r.values_written == 0 and r.bytes_consumed == 0:
+        if r.status != OK and r.values_written == 0 and r.bytes_consumed == 0 and self._encoding != ENC_PLAIN_BYTE_ARRAY:
             _raise_for(r.status, type(self).__name__ + ".initFromPage")  # a length block failed
         self._status = r.status
         self._values = _np.arange(r.values_written)
@@ -590,6 +590,16 @@ class DeltaLengthByteArrayValuesReader(ValuesReader):
     def skip(self, n=1):
         for _ in range(n):
             self._next()
+
+
+class BinaryPlainValuesReader(DeltaLengthByteArrayValuesReader):
+    """BinaryPlainValuesReader.java:36-74: every value is its length (four bytes, little-endian) and its bytes;
+    ``readBytes`` of a value that does not lie inside the page raises ParquetDecodingException ("could not read
+    bytes at offset").  The whole page is decoded in ``initFromPage``; a failure shows at the value it belongs to."""
+    _encoding = ENC_PLAIN_BYTE_ARRAY
+
+    def _fail_at_end(self):
+        raise ParquetDecodingException("could not read bytes at offset %d" % self._offsets[len(self._values)])
 
 
 class DeltaByteArrayReader(DeltaLengthByteArrayValuesReader):

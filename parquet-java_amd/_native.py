@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("PQD_LIB_PATH") or os.path.join(_HERE, "lib", "libpqde
 OK, EOF, BAD_ARG, PAST_END, DECODE, DICT_OOB, HIP_ERROR, NO_DEVICE = range(8)
 ENC_RLE, ENC_RLE_DICTIONARY, ENC_DELTA_BINARY_PACKED, ENC_BYTE_STREAM_SPLIT, ENC_BIT_PACKED = 1, 2, 3, 4, 5
 ENC_PLAIN, ENC_PLAIN_BOOLEAN = 6, 7
-ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY = 8, 9
+ENC_DELTA_LENGTH_BYTE_ARRAY, ENC_DELTA_BYTE_ARRAY, ENC_PLAIN_BYTE_ARRAY = 8, 9, 10
 F_LENGTH_PREFIX, F_WIDTH_PREFIX = 1, 2
 TYPE_BOOLEAN, TYPE_INT32, TYPE_INT64, TYPE_INT96, TYPE_FLOAT, TYPE_DOUBLE, TYPE_BYTE_ARRAY, TYPE_FIXED_LEN_BYTE_ARRAY = 0, 1, 2, 3, 4, 5, 6, 7
 PAGE_DATA, PAGE_INDEX, PAGE_DICTIONARY, PAGE_DATA_V2 = 0, 1, 2, 3

@@ -536,6 +536,7 @@ __global__ __launch_bounds__(DELTA_THREADS) void k_delta_length_blocks(const pqd
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_delta_bytes_desc b = descs[page];
+  if (b.encoding == PQD_ENC_PLAIN_BYTE_ARRAY) return;  // no length blocks (and no work area)
   pqd_page_result* rec = reinterpret_cast<pqd_page_result*>(b.work);
   int32_t* lengths = reinterpret_cast<int32_t*>(b.work + DELTA_BYTES_WORK_HEADER);
   pqd_page_desc d{};

@@ -1057,6 +1057,7 @@ int pqd_delta_byte_array_dev(const pqd_delta_bytes_desc* descs, pqd_page_result*
   if (!descs || !results) return fail(PQD_BAD_ARG, "null descriptor / result array");
   PQD_HIP(pqd::launch_delta_length_blocks(descs, n_pages, as_stream(stream)));
   PQD_HIP(pqd::launch_delta_bytes(descs, results, n_pages, as_stream(stream)));
+  PQD_HIP(pqd::launch_plain_byte_array(descs, results, n_pages, as_stream(stream)));
   return PQD_OK;
 }
 
@@ -1064,8 +1065,8 @@ int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t
                                      const uint8_t* previous, uint32_t previous_len, int32_t* offsets, uint8_t* bytes,
                                      uint32_t bytes_capacity, pqd_page_result* result, uint64_t* bytes_needed) {
   if (!result || !offsets) return fail(PQD_BAD_ARG, "null result / offsets");
-  if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY)
-    return fail(PQD_BAD_ARG, "not a delta byte array encoding");
+  if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY && encoding != PQD_ENC_PLAIN_BYTE_ARRAY)
+    return fail(PQD_BAD_ARG, "not a BYTE_ARRAY value encoding (PLAIN_BYTE_ARRAY, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY are)");
   if ((page_len && !page) || (bytes_capacity && !bytes) || (previous_len && !previous))
     return fail(PQD_BAD_ARG, "null page / output / previous value");
   int st = check_device_available();
@@ -1100,23 +1101,35 @@ int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t
     d.prev_offsets = (const int32_t*)(d_in + page_padded + prev_padded);
     d.prev_count = 1;
   }
-  // the length blocks first: their sum is the room the values need
-  PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
-  PQD_HIP(pqd::launch_delta_length_blocks((const pqd_delta_bytes_desc*)c.descs.p, 1, s));
-  const int blocks = encoding == PQD_ENC_DELTA_BYTE_ARRAY ? 2 : 1;
-  std::vector<int32_t> lengths((size_t)num_values * blocks);
-  pqd_page_result block_result[2] = {};
-  PQD_HIP(hipMemcpyAsync(block_result, c.out.p, sizeof block_result, hipMemcpyDeviceToHost, s));
-  if (!lengths.empty())
-    PQD_HIP(hipMemcpyAsync(lengths.data(), (uint8_t*)c.out.p + 64, lengths.size() * 4, hipMemcpyDeviceToHost, s));
-  PQD_HIP(hipStreamSynchronize(s));
   uint64_t need = 0;
-  for (int b = 0; b < blocks; ++b) {
-    if (block_result[b].status != PQD_OK) break;  // the page fails before its first value
-    const uint32_t have = block_result[b].values_written < num_values ? block_result[b].values_written : num_values;
-    for (uint32_t i = 0; i < have; ++i) {
-      const int32_t v = lengths[(size_t)b * num_values + i];
-      need += v > 0 ? (uint64_t)v : 0u;
+  if (encoding == PQD_ENC_PLAIN_BYTE_ARRAY) {
+    // a pass that leaves the bytes where they are: the room the values need
+    if ((st = c.dict.ensure(offs_padded + 32))) return st;
+    d.offsets = (int32_t*)c.dict.p;
+    PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
+    PQD_HIP(pqd::launch_plain_byte_array((const pqd_delta_bytes_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, s));
+    pqd_page_result in_place = {};
+    PQD_HIP(hipMemcpyAsync(&in_place, c.results.p, sizeof in_place, hipMemcpyDeviceToHost, s));
+    PQD_HIP(hipStreamSynchronize(s));
+    need = in_place.reserved;
+  } else {
+    // the length blocks first: their sum is the room the values need
+    PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
+    PQD_HIP(pqd::launch_delta_length_blocks((const pqd_delta_bytes_desc*)c.descs.p, 1, s));
+    const int blocks = encoding == PQD_ENC_DELTA_BYTE_ARRAY ? 2 : 1;
+    std::vector<int32_t> lengths((size_t)num_values * blocks);
+    pqd_page_result block_result[2] = {};
+    PQD_HIP(hipMemcpyAsync(block_result, c.out.p, sizeof block_result, hipMemcpyDeviceToHost, s));
+    if (!lengths.empty())
+      PQD_HIP(hipMemcpyAsync(lengths.data(), (uint8_t*)c.out.p + 64, lengths.size() * 4, hipMemcpyDeviceToHost, s));
+    PQD_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < blocks; ++b) {
+      if (block_result[b].status != PQD_OK) break;  // the page fails before its first value
+      const uint32_t have = block_result[b].values_written < num_values ? block_result[b].values_written : num_values;
+      for (uint32_t i = 0; i < have; ++i) {
+        const int32_t v = lengths[(size_t)b * num_values + i];
+        need += v > 0 ? (uint64_t)v : 0u;
+      }
     }
   }
   if (bytes_needed) *bytes_needed = need;
@@ -1126,7 +1139,10 @@ int pqd_decode_delta_byte_array_page(int encoding, const uint8_t* page, uint32_t
   d.bytes = (uint8_t*)c.dict.p + offs_padded;
   d.bytes_capacity = (uint32_t)room;
   PQD_HIP(hipMemcpyAsync(c.descs.p, &d, sizeof d, hipMemcpyHostToDevice, s));
-  PQD_HIP(pqd::launch_delta_bytes((const pqd_delta_bytes_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, s));
+  if (encoding == PQD_ENC_PLAIN_BYTE_ARRAY)
+    PQD_HIP(pqd::launch_plain_byte_array((const pqd_delta_bytes_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, s));
+  else
+    PQD_HIP(pqd::launch_delta_bytes((const pqd_delta_bytes_desc*)c.descs.p, (pqd_page_result*)c.results.p, 1, s));
   PQD_HIP(hipMemcpyAsync(result, c.results.p, sizeof *result, hipMemcpyDeviceToHost, s));
   PQD_HIP(hipStreamSynchronize(s));
   PQD_HIP(hipMemcpyAsync(offsets, d.offsets, ((size_t)result->values_written + 1) * 4, hipMemcpyDeviceToHost, s));

@@ -383,6 +383,9 @@ __global__ __launch_bounds__(256) void k_chunk_sections(const pqd_chunk_page* __
         out_elem = 1;
       } else if (fixed) {
         enc = PQD_ENC_PLAIN;
+      } else if (col.physical_type == PQD_TYPE_BYTE_ARRAY) {
+        enc = PQD_ENC_PLAIN_BYTE_ARRAY;  // Encoding.PLAIN.getValuesReader: BinaryPlainValuesReader (Encoding.java:63-86)
+        out_elem = 0;
       }
       break;
     case PQD_FMT_RLE:  // booleans: RunLengthBitPackingHybridValuesReader(1), length-prefixed (Encoding.java:119-145)
@@ -410,15 +413,29 @@ __global__ __launch_bounds__(256) void k_chunk_sections(const pqd_chunk_page* __
     case PQD_FMT_BYTE_STREAM_SPLIT:
       if (fixed) enc = PQD_ENC_BYTE_STREAM_SPLIT;
       break;
+    case PQD_FMT_DELTA_LENGTH_BYTE_ARRAY:  // Encoding.java:204-217: BYTE_ARRAY only
+      if (col.physical_type == PQD_TYPE_BYTE_ARRAY) {
+        enc = PQD_ENC_DELTA_LENGTH_BYTE_ARRAY;
+        out_elem = 0;
+      }
+      break;
+    case PQD_FMT_DELTA_BYTE_ARRAY:  // Encoding.java:219-232: BYTE_ARRAY and FIXED_LEN_BYTE_ARRAY
+      if (col.physical_type == PQD_TYPE_BYTE_ARRAY || col.physical_type == PQD_TYPE_FIXED_LEN_BYTE_ARRAY) {
+        enc = PQD_ENC_DELTA_BYTE_ARRAY;
+        out_elem = 0;
+      }
+      break;
     default:
-      break;  // DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY / PLAIN BYTE_ARRAY: not value pages of fixed width
+      break;
   }
+  // (the three BYTE_ARRAY encodings: elem_size 0, `out` not set; the caller makes a pqd_delta_bytes_desc of data,
+  // data_len, num_values and encoding)
   v.data = body + pos;
   v.data_len = status == PQD_OK ? size - pos : 0u;
   v.num_values = n;
   v.encoding = (uint8_t)enc;
   v.elem_size = (uint8_t)out_elem;
-  v.out = o.val_out ? (uint8_t*)o.val_out + (size_t)(o.value_base ? o.value_base[i] : lbase) * out_elem : nullptr;
+  v.out = o.val_out && out_elem ? (uint8_t*)o.val_out + (size_t)(o.value_base ? o.value_base[i] : lbase) * out_elem : nullptr;
   if (enc == PQD_ENC_RLE_DICTIONARY) {
     v.dict = o.dict;
     v.dict_len = o.dict_len;

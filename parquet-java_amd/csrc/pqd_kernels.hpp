@@ -53,6 +53,8 @@ hipError_t launch_delta_pages(const pqd_page_desc* descs, pqd_page_result* resul
 constexpr uint32_t DELTA_BYTES_WORK_HEADER = 64;
 hipError_t launch_delta_length_blocks(const pqd_delta_bytes_desc* descs, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_delta_bytes(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
+// PLAIN BYTE_ARRAY pages among the same descriptors (encoding PQD_ENC_PLAIN_BYTE_ARRAY; the other pages are left alone)
+hipError_t launch_plain_byte_array(const pqd_delta_bytes_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 // SNAPPY / LZ4_RAW / ZSTD pages (one wave each) and stored parts (desc.codec PQD_CODEC_UNCOMPRESSED)
 hipError_t launch_gzip_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);
 hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cuts level streams and dictionary-id pages out of the .parquet files that parquet-java itself wrote
+"""Cuts level streams, dictionary-id pages and PLAIN value pages out of the .parquet files that parquet-java itself wrote
 (the reference's own test resources) and stores them, with their expected decoded values, in
 ``java_pages.json``.  Run in the build container, where /root/reference exists:
 
@@ -23,6 +23,7 @@ FILES = [
     "parquet-hadoop/src/test/resources/test-append_1.parquet",
     "parquet-hadoop/src/test/resources/test-append_2.parquet",
     "parquet-hadoop/src/test/resources/test-file-with-no-column-indexes-1.parquet",
+    "parquet-avro/src/test/resources/strings-2.parquet",
 ]
 PLAIN_FMT = {"INT32": ("i", 4), "INT64": ("q", 8), "DOUBLE": ("d", 8), "FLOAT": ("f", 4)}
 ENCODINGS = {0: "PLAIN", 2: "PLAIN_DICTIONARY", 3: "RLE", 4: "BIT_PACKED", 5: "DELTA_BINARY_PACKED",
@@ -221,6 +222,19 @@ def main():
                                              elem_size=size, data=bytes(sect).hex(), num_values=n_present,
                                              expected_hex=bytes(sect[:n_present * size]).hex()))
                         plain_values += vals
+                    elif enc == "PLAIN" and cc.physical_type == "BYTE_ARRAY":
+                        # PLAIN BYTE_ARRAY values as parquet-java wrote them: [length: 4 bytes LE][bytes] ...
+                        sect = payload[q:]
+                        vals, at = [], 0
+                        for _ in range(n_present):
+                            ln = struct.unpack_from("<i", sect, at)[0]
+                            vals.append(bytes(sect[at + 4:at + 4 + ln]))
+                            at += 4 + ln
+                        assert at == len(sect)
+                        fixtures.append(dict(base, kind="plain_byte_array", encoding="PLAIN", physical_type="BYTE_ARRAY",
+                                             data=bytes(sect).hex(), num_values=n_present,
+                                             expected=[v.decode("latin-1") for v in vals]))
+                        decoded_strings += vals  # compared with pyarrow's reading of the column below
                     page_no += 1
                 # ---- cross-checks against pyarrow's reading of the same chunk
                 name = cc.path_in_schema
@@ -252,7 +266,7 @@ def main():
     # whole column chunks of the same files (page headers included), for the page-header walk
     import base64
     chunks = []
-    for rel in FILES + ["parquet-avro/src/test/resources/strings-2.parquet"]:
+    for rel in FILES:
         path = os.path.join(REF, rel)
         buf = open(path, "rb").read()
         pf = pq.ParquetFile(path)

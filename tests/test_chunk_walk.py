@@ -99,8 +99,12 @@ def test_walk_failures():
 PHYS = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "INT96": 3, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6, "FIXED_LEN_BYTE_ARRAY": 7}
 CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "LZ4": 7, "ZSTD": 6, "GZIP": 2}  # (pyarrow's metadata calls LZ4_RAW "LZ4")
 WHOLE = [fx for fx in ARROW if fx["codec"] in CODECS and fx["max_rep"] == 0 and
-         fx["physical_type"] in ("INT32", "INT64", "FLOAT", "DOUBLE", "BOOLEAN", "FIXED_LEN_BYTE_ARRAY") and
-         not ({"DELTA_LENGTH_BYTE_ARRAY", "DELTA_BYTE_ARRAY"} & set(fx["encodings"]))]
+         fx["physical_type"] in ("INT32", "INT64", "FLOAT", "DOUBLE", "BOOLEAN", "FIXED_LEN_BYTE_ARRAY", "BYTE_ARRAY")]
+
+
+def test_whole_chunk_cases_cover_the_byte_array_encodings():
+    kinds = {tuple(sorted(set(fx["encodings"]) - {"RLE"})) for fx in WHOLE if fx["physical_type"] == "BYTE_ARRAY"}
+    assert {("PLAIN",), ("PLAIN", "RLE_DICTIONARY"), ("DELTA_LENGTH_BYTE_ARRAY",), ("DELTA_BYTE_ARRAY",)} <= kinds
 
 
 @pytest.mark.gpu
@@ -116,7 +120,8 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     st, pages, n = walk(pq, chunk, fx["num_values"])
     assert st == 0
     d_chunk = gh.to_dev(np.concatenate([np.frombuffer(chunk, np.uint8), np.zeros(64, np.uint8)]))
-    elem = {"INT32": 4, "INT64": 8, "FLOAT": 4, "DOUBLE": 8, "BOOLEAN": 1, "FIXED_LEN_BYTE_ARRAY": fx["type_length"]}[fx["physical_type"]]
+    binary = fx["physical_type"] == "BYTE_ARRAY"
+    elem = {"INT32": 4, "INT64": 8, "FLOAT": 4, "DOUBLE": 8, "BOOLEAN": 1, "FIXED_LEN_BYTE_ARRAY": fx["type_length"], "BYTE_ARRAY": 8}[fx["physical_type"]]
     d_bodies = d_chunk
     if CODECS[fx["codec"]]:
         # compressed pages: every body is decompressed on the device into one buffer, which then is the chunk
@@ -133,12 +138,16 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
         assert all(p.is_compressed == 0 and p.compressed_size == p.uncompressed_size for p in pages)
     dict_page = [p for p in pages if p.type == pq.PAGE_DICTIONARY]
     data_pages = [p for p in pages if p.type != pq.PAGE_DICTIONARY]
-    d_dict, dict_len = None, 0
+    d_dict, dict_len, handle, info = None, 0, C.c_void_p(), pq.DictInfo()
     if dict_page:
         p = dict_page[0]
         body = d_bodies.cpu().numpy()[p.body_offset:p.body_offset + p.compressed_size]
         d_dict = gh.to_dev(np.concatenate([body, np.zeros(16, np.uint8)]))  # PLAIN fixed-width dictionary page = the entries
         dict_len = p.num_values
+        if binary:  # entries = views into the dictionary page's bytes (pqd_dict_create walks the page)
+            body = np.ascontiguousarray(body)
+            pq.check(pq.lib.pqd_dict_create(PHYS["BYTE_ARRAY"], 0, body.ctypes.data, body.size, p.num_values, C.byref(handle)))
+            pq.check(pq.lib.pqd_dict_get(handle, C.byref(info)))
     table = (pq.ChunkPage * len(data_pages))(*data_pages)
     d_table = gh.to_dev(np.frombuffer(bytes(table), np.uint8).copy())
     n_pages = len(data_pages)
@@ -150,7 +159,7 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     d_val = torch.zeros(max(total, 1) * max(out_elem, elem) + 64, dtype=torch.uint8, device=gh.dev())
     meta = pq.ColumnMeta(PHYS[fx["physical_type"]], fx["type_length"], fx["max_def"], 0)
     outs = pq.ChunkOutputs(d_bodies.data_ptr(), 0, d_def.data_ptr(), d_val.data_ptr(), d_base.data_ptr(), d_base.data_ptr(),
-                           0 if d_dict is None else d_dict.data_ptr(), dict_len, 0)
+                           0 if d_dict is None else (info.entries if binary else d_dict.data_ptr()), dict_len, 0)
     descs = [torch.zeros(n_pages * 40, dtype=torch.uint8, device=gh.dev()) for _ in range(3)]
     res = [torch.zeros(n_pages * 16, dtype=torch.uint8, device=gh.dev()) for _ in range(4)]
     pq.check(pq.lib.pqd_chunk_sections_dev(d_table.data_ptr(), n_pages, C.byref(meta), C.byref(outs), descs[0].data_ptr(),
@@ -182,6 +191,70 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     encs = val_descs[:, 36]
     assert (encs != 0).all()
     order = np.argsort(encs, kind="stable")
+    counts = res[2].cpu().numpy().view(np.uint32).reshape(-1, 4)[:, 3]
+    if binary:
+        # BYTE_ARRAY values -> offsets + bytes per page: dictionary pages in one launch (ids, dictionary entries and
+        # bytes in one pass), the PLAIN / DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY pages in another
+        want = pf.fixture_values(fx)
+        room = sum(len(v) for v in want) + 64
+        d_offs = torch.full((total + n_pages + 8,), -7, dtype=torch.int32, device=gh.dev())
+        d_bytes = torch.zeros(n_pages * room, dtype=torch.uint8, device=gh.dev())
+        fields = val_descs.view(np.uint64).reshape(n_pages, 5)[:, 0], val_descs.view(np.uint32).reshape(n_pages, 10)
+        got_status = np.zeros(n_pages, np.int64)
+        got_written = np.zeros(n_pages, np.int64)
+        dict_pages = [i for i in range(n_pages) if encs[i] == pq.ENC_RLE_DICTIONARY]
+        other_pages = [i for i in range(n_pages) if encs[i] != pq.ENC_RLE_DICTIONARY]
+        assert all(encs[i] in (8, 9, 10) and val_descs[i, 37] == 0 for i in other_pages)
+        if dict_pages:
+            bins = (pq.BinaryPageDesc * len(dict_pages))()
+            for k, i in enumerate(dict_pages):
+                assert val_descs[i, 37] == 8 and fields[1][i, 8] == dict_len
+                bins[k].dict_bytes, bins[k].dict_bytes_len = info.bytes, info.bytes_len
+                bins[k].offsets = d_offs.data_ptr() + 4 * (int(level_base[i]) + i)
+                bins[k].bytes, bins[k].bytes_capacity = d_bytes.data_ptr() + i * room, room
+            d_bins = gh.to_dev(np.frombuffer(bytes(bins), np.uint8).copy())
+            d_pages = gh.to_dev(val_descs[dict_pages].reshape(-1))
+            r2 = [torch.zeros(len(dict_pages) * 16, dtype=torch.uint8, device=gh.dev()) for _ in range(2)]
+            pq.check(pq.lib.pqd_decode_binary_pages_dev(handle, d_pages.data_ptr(), d_bins.data_ptr(), r2[0].data_ptr(), r2[1].data_ptr(),
+                                                        len(dict_pages), None))
+            torch.cuda.synchronize()
+            for r in r2:
+                st, wr, _ = pq.results_from_numpy(r.cpu().numpy())
+                got_status[dict_pages] |= st
+                got_written[dict_pages] = wr
+        if other_pages:
+            dd = (pq.DeltaBytesDesc * len(other_pages))()
+            works = []
+            for k, i in enumerate(other_pages):
+                nv = int(fields[1][i, 7])
+                works.append(torch.zeros(pq._native.delta_bytes_work(nv) + 16, dtype=torch.uint8, device=gh.dev()))
+                dd[k].data, dd[k].data_len, dd[k].num_values, dd[k].encoding = int(fields[0][i]), int(fields[1][i, 6]), nv, int(encs[i])
+                dd[k].offsets = d_offs.data_ptr() + 4 * (int(level_base[i]) + i)
+                dd[k].bytes, dd[k].bytes_capacity = d_bytes.data_ptr() + i * room, room
+                dd[k].work = works[-1].data_ptr()
+            d_dd = gh.to_dev(np.frombuffer(bytes(dd), np.uint8).copy())
+            r3 = torch.zeros(len(other_pages) * 16, dtype=torch.uint8, device=gh.dev())
+            pq.check(pq.lib.pqd_delta_byte_array_dev(d_dd.data_ptr(), r3.data_ptr(), len(other_pages), None))
+            torch.cuda.synchronize()
+            st, wr, _ = pq.results_from_numpy(r3.cpu().numpy())
+            got_status[other_pages], got_written[other_pages] = st, wr
+        assert (got_status == 0).all() and (got_written == counts).all()
+        offs, data = d_offs.cpu().numpy(), d_bytes.cpu().numpy()
+        got = []
+        for i in range(n_pages):
+            o = offs[int(level_base[i]) + i:int(level_base[i]) + i + int(counts[i]) + 1]
+            page_bytes = data[i * room:(i + 1) * room]
+            got += [page_bytes[a:b].tobytes() for a, b in zip(o[:-1], o[1:])]
+        assert got == want
+        if handle:
+            pq.check(pq.lib.pqd_dict_destroy(handle))
+        want_present = pf.fixture_present(fx)
+        if want_present is not None:
+            validity = d_validity.cpu().numpy()
+            bits = np.concatenate([np.unpackbits(validity[s:s + (p.num_values + 7) // 8], bitorder="little")[:p.num_values]
+                                   for s, p in zip(vstarts, data_pages)]).astype(bool)
+            assert (bits == want_present).all()
+        return
     sorted_descs = gh.to_dev(val_descs[order].reshape(-1))
     sorted_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=gh.dev())
     a = 0
@@ -195,8 +268,6 @@ def test_gpu_whole_chunk_from_one_blob(orc, fx):
     torch.cuda.synchronize()
     status, written, _ = pq.results_from_numpy(sorted_res.cpu().numpy())
     assert (status == 0).all()
-    non_null = pq.results_from_numpy(res[2].cpu().numpy())
-    counts = res[2].cpu().numpy().view(np.uint32).reshape(-1, 4)[:, 3]
     assert (written == counts[order]).all()
     # gather the dense values page by page and compare with pyarrow's
     val = d_val.cpu().numpy()

@@ -29,6 +29,8 @@ def test_oracle_decodes_java_written_pages(orc):
             assert st == 0 and vals.tobytes().hex() == f["expected_hex"], f["column"]
             assert orc.plain_decode(data, f["elem_size"], f["num_values"] + 1)[0] == orc.DECODE  # "could not read ..."
             continue
+        if f["kind"] == "plain_byte_array":  # tests/test_plain_binary.py
+            continue
         exp = np.array(f["expected"], np.int32)
         if f["kind"] == "dictionary_ids":
             st, ids = orc.dict_decode_ids(data, exp.size)
