@@ -4,7 +4,7 @@ ARCH ?= gfx950
 PKG := parquet-java_amd
 CSRC := $(PKG)/csrc
 LIB := $(PKG)/lib/libpqdecode_hip.so
-SRCS := $(CSRC)/pqd_api.hip $(CSRC)/pqd_chunk.hip $(CSRC)/k_dict_planes.hip $(CSRC)/k_unpack.hip $(CSRC)/k_rle.hip $(CSRC)/k_rle_plan.hip $(CSRC)/k_rle_small.hip $(CSRC)/k_rle_expand.hip $(CSRC)/k_dict_sliced.hip $(CSRC)/k_delta.hip $(CSRC)/k_bss.hip $(CSRC)/k_binary.hip $(CSRC)/k_binary_fused.hip $(CSRC)/k_plain.hip $(CSRC)/k_plain_binary.hip $(CSRC)/k_levels.hip $(CSRC)/k_delta_bytes.hip $(CSRC)/k_lz.hip $(CSRC)/k_zstd.hip $(CSRC)/k_gzip.hip
+SRCS := $(CSRC)/pqd_api.hip $(CSRC)/pqd_chunk.hip $(CSRC)/k_unpack.hip $(CSRC)/k_rle.hip $(CSRC)/k_rle_plan.hip $(CSRC)/k_rle_small.hip $(CSRC)/k_rle_expand.hip $(CSRC)/k_dict_sliced.hip $(CSRC)/k_delta.hip $(CSRC)/k_bss.hip $(CSRC)/k_binary.hip $(CSRC)/k_binary_fused.hip $(CSRC)/k_plain.hip $(CSRC)/k_plain_binary.hip $(CSRC)/k_levels.hip $(CSRC)/k_delta_bytes.hip $(CSRC)/k_lz.hip $(CSRC)/k_zstd.hip $(CSRC)/k_gzip.hip
 HDRS := include/pqd.h $(CSRC)/pqd_rle_scan.hpp $(CSRC)/pqd_device.hpp $(CSRC)/pqd_kernels.hpp $(CSRC)/pqd_rle_plan.hpp $(CSRC)/pqd_lz_common.hpp $(CSRC)/pqd_expand.hpp $(CSRC)/pqd_whole_page.hpp
 HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 
@@ -32,7 +32,7 @@ $(CPPTEST): tests/cpp/test_readers.cpp include/pqd_readers.hpp include/pqd.h $(L
 
 asm: $(SRCS) $(HDRS)
 	@mkdir -p build/asm
-	cd build/asm && for f in k_dict_planes k_unpack k_rle k_rle_plan k_rle_small k_rle_expand k_dict_sliced k_delta k_bss k_binary k_plain k_levels k_delta_bytes k_lz k_zstd; do \
+	cd build/asm && for f in k_unpack k_rle k_rle_plan k_rle_small k_rle_expand k_dict_sliced k_delta k_bss k_binary k_plain k_levels k_delta_bytes k_lz k_zstd; do \
 	  $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o $$f.s ../../$(CSRC)/$$f.hip -Rpass-analysis=kernel-resource-usage 2> $$f.usage.txt; done
 
 # development build with per-phase cycle counters in the sliced dictionary kernel (load it with PQD_LIB_PATH)

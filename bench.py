@@ -658,7 +658,7 @@ def main():
                                       "frac": round(ach64 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                       "algorithmic_bytes_per_launch": k64_alg_bytes, "avg_launch_ms": round(gather_ms, 4),
                                       "launches_timed": gather_calls,
-                                      "other_launches_ms": {"k_dict_slots + k_rle_plan + k_dict_planes": round(plan_ms, 4),
+                                      "other_launches_ms": {"k_dict_slots + k_rle_plan_chunks": round(plan_ms, 4),
                                                             "k_rle_pages (left-over pages)": round(rest_ms, 4),
                                                             "note": "timed after the region, five more steps"}},
         }

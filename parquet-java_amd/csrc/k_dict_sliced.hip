@@ -17,7 +17,7 @@
 //   - each pass looks up the ids that fall into the resident slice (their values go to registers
 //     of their own; an id is found by exactly one pass).  4-byte dictionaries are swept as they
 //     are; 8-byte dictionaries are swept as two dword PLANES (a copy made once per call by
-//     k_dict_planes: all low dwords, then all high dwords), a quarter of a plane (16384 entries,
+//     dict_plane_piece: all low dwords, then all high dwords), a quarter of a plane (16384 entries,
 //     64 KiB) per pass, so that an id's LDS address is the same in every pass and a lookup is one
 //     byte-selecting compare that puts the quarter's lanes into EXEC plus one 4-byte LDS read;
 //   - while one page is being gathered, the next page's plan, segments and packed dwords are

@@ -35,9 +35,6 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
 // for every page (PLAN_F_SMALL_DONE where it decoded the page)
 hipError_t launch_rle_small_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t n_pages,
                                   hipStream_t stream);
-// fills the plane slots k_dict_slots claimed (their number: cursor[2]); the plan kernel's launch does the same for
-// the calls that go through it (the piece routine is shared: dict_plane_piece in pqd_rle_plan.hpp)
-hipError_t launch_dict_planes(const DictPlanes& planes, const uint32_t* cursor, hipStream_t stream);
 // plain hybrid pages: expansion of all chunks
 hipError_t launch_rle_expand(const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t n_pages,
                              hipStream_t stream);

@@ -114,7 +114,7 @@ constexpr uint32_t DS_MAX_PASSES = 32;
 // piece for the LDS-DMA.  The plan kernel finds or claims the slot of a page's dictionary in a small
 // open-addressing table keyed by the dictionary's address and length (`keys`, zeroed per call), and
 // lists the slots it claimed (`list`, their number in counter 2 of the call's counter block);
-// k_dict_planes then fills them, and the chunk headers carry the slot to the gather.
+// the plan kernel (dict_plane_piece) then fills them, and the chunk headers carry the slot to the gather.
 constexpr uint32_t DP_PLANE_BYTES = 256 * 1024;
 constexpr uint32_t DP_SLOT_BYTES = 2 * DP_PLANE_BYTES;
 constexpr uint32_t DP_QUARTER_ENTRIES = 16384;
