@@ -232,18 +232,50 @@ def cpu_baseline(seconds, seed, threads=1):
                       f"{threads} thread(s), {dt:.1f} s"}
 
 
+def splitmix64(index, seed):
+    """splitmix64 of (seed + index) as int64 bit patterns (torch's int64 arithmetic wraps)."""
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    def wrap(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+    z = (index + seed + 1) * wrap(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * wrap(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * wrap(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
 def config1_sweep(device, stream, timed, n_pages=256, n_values=1_000_000):
     """BASELINE.json configs[0] on the device: `n_pages` distinct pages of `n_values` INT32 values per bit
-    width 1..32, RLE / bit-packing hybrid as parquet-java writes non-repeating data (bit-packed runs of 63
-    groups = 504 values behind 1-byte headers, RunLengthBitPackingHybridEncoder.java:185-235), decoded by
-    one pqd_decode_pages_dev call per width.  Payload bytes are random, which makes the values random
-    w-bit numbers; two pages per width are re-derived from the payload bits with torch and compared."""
+    width 1..32, RLE / bit-packing hybrid, decoded by one pqd_decode_pages_dev call per width.  Two flavours:
+    A ("all_bit_packed"): random payload bytes behind 1-byte headers of 63 groups = 504 values
+       (RunLengthBitPackingHybridEncoder.java:185-235 for data without repeats); two pages per width are re-derived
+       from the payload bits with torch and compared.
+    B ("java_encoder_layout"): values = splitmix64 & (2^w - 1), laid out as RunLengthBitPackingHybridEncoder
+       (:146-273) writes those values (synth_pages.hybrid_encode: eight or more equal values from a group boundary
+       become an RLE run, which at widths 1..3 is common); every decoded value is compared with its source."""
+    import synth_pages as sp
     groups = n_values // 8
     full, tail = divmod(groups, 63)
     out = torch.empty((n_pages, n_values), dtype=torch.int32, device=device)
     g = torch.Generator(device=device)
-    res = {}
+    res, res_b = {}, {}
+
+    def line(ms, encoded, ok, **more):
+        alg = encoded + n_pages * n_values * 4
+        return dict({"ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
+                     "decoded_GBps": round(n_pages * n_values * 4 / ms / 1e6, 1), "verified": ok}, **more)
+
+    def run(descs_fields):
+        d_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(descs_fields))).to(device)
+        d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
+        out.zero_()
+        ms = timed(lambda: pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n_pages, pq.ENC_RLE, 4, stream), iters=5)
+        status, written, _ = pq.results_from_numpy(d_res.cpu().numpy())
+        return ms, bool((status == 0).all() and (written == n_values).all())
+
     for w in range(1, 33):
+        # ---- flavour A
         g.manual_seed(42 + w)
         payload = torch.randint(0, 256, (n_pages, groups * w), dtype=torch.uint8, device=device, generator=g)
         parts = []
@@ -256,26 +288,29 @@ def config1_sweep(device, stream, timed, n_pages=256, n_values=1_000_000):
             parts.append(payload[:, full * 63 * w:])
         blob = torch.cat(parts, 1).contiguous()
         page_len = blob.shape[1]
-        pages = [dict(data=blob.data_ptr() + i * page_len, out=out.data_ptr() + i * n_values * 4, data_len=page_len,
-                      num_values=n_values, encoding=pq.ENC_RLE, elem_size=4, bit_width=w) for i in range(n_pages)]
-        d_descs = torch.from_numpy(pq.descs_to_numpy(pq.make_descs(pages))).to(device)
-        d_res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
-        out.zero_()
-        ms = timed(lambda: pq.decode_pages_dev(d_descs.data_ptr(), d_res.data_ptr(), n_pages, pq.ENC_RLE, 4, stream), iters=5)
-        status, written, _ = pq.results_from_numpy(d_res.cpu().numpy())
-        ok = bool((status == 0).all() and (written == n_values).all())
+        ms, ok = run([dict(data=blob.data_ptr() + i * page_len, out=out.data_ptr() + i * n_values * 4, data_len=page_len,
+                           num_values=n_values, encoding=pq.ENC_RLE, elem_size=4, bit_width=w) for i in range(n_pages)])
         for i in (0, n_pages - 1):
             bits = ((payload[i].to(torch.int64)[:, None] >> torch.arange(8, device=device)) & 1).reshape(-1, w)
             vals = (bits << torch.arange(w, device=device)).sum(1).to(torch.int32)  # width 32 wraps to the bit pattern
             ok = ok and bool(torch.equal(vals, out[i]))
             del bits, vals
-        alg = n_pages * (page_len + n_values * 4)
-        res[str(w)] = {"ms": round(ms, 4), "algorithmic_GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / HBM_PEAK_GBS, 3),
-                       "decoded_GBps": round(n_pages * n_values * 4 / ms / 1e6, 1), "verified": ok}
-        del payload, blob, parts, d_descs, d_res
+        res[str(w)] = line(ms, n_pages * page_len, ok)
+        del payload, blob, parts
+        # ---- flavour B
+        values = splitmix64(torch.arange(n_pages * n_values, dtype=torch.int64, device=device), 1000 * w) & ((1 << w) - 1)
+        blob, offs = sp.hybrid_encode_chunked(values.view(n_pages, n_values), w, pages_per_call=32)
+        blob = torch.cat([blob, torch.zeros(64, dtype=torch.uint8, device=device)])
+        o = offs.tolist()
+        ms, ok = run([dict(data=blob.data_ptr() + o[i], out=out.data_ptr() + i * n_values * 4, data_len=o[i + 1] - o[i],
+                           num_values=n_values, encoding=pq.ENC_RLE, elem_size=4, bit_width=w) for i in range(n_pages)])
+        ok = ok and bool(torch.equal(out.view(-1), values.to(torch.int32)))
+        res_b[str(w)] = line(ms, o[-1], ok, encoded_bytes_per_page=round(o[-1] / n_pages, 1))
+        del values, blob, offs
     del out
     torch.cuda.empty_cache()
-    return {"pages": n_pages, "values_per_page": n_values, "by_bit_width": res,
+    return {"pages": n_pages, "values_per_page": n_values, "by_bit_width": res, "flavour_of_by_bit_width": "A: all bit-packed, random payload",
+            "java_encoder_layout_by_bit_width": res_b,
             "note": "algorithmic bytes = encoded page + 4 bytes per value; distinct pages (2.0 GiB decoded per call: beyond the 256 MiB Infinity Cache)"}
 
 

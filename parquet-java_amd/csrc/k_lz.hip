@@ -5,157 +5,510 @@
 // i.e. SnappyDecompressor.uncompress -> org.xerial.snappy.Snappy.uncompress (codec/SnappyDecompressor.java:
 // 27-35) and Lz4RawDecompressor.uncompress -> io.airlift.compress.lz4.Lz4Decompressor (codec/
 // Lz4RawDecompressor.java:29-49).  Both formats are a byte-serial stream of "copy these literal bytes" and
-// "repeat `length` bytes from `offset` back" elements, so a page is one serial chain; pages are
-// independent.  One wave per page.  Snappy is taken 64 input bytes at a time (snappy_window below: every byte
-// position is tried as an element header, the real chain is found by lane exchanges, literal bytes move in
-// one step, copies one after the other); LZ4 sequences, and Snappy streams in which something is out of
-// order, go element by element: the headers are decoded wave-uniformly (scalar registers, read from a
-// 16-byte window of the input kept there), the 64 lanes move the bytes.  The input is staged in LDS in 2 KiB
-// chunks, the next chunk already on its way in registers; the last 16 KiB of output are kept in an LDS ring,
-// which is where most matches read from; a match from further back reads the bytes back from L2.
-// Lane l of a match step takes the byte `offset` back, or for offsets below 64 the byte (l mod offset) -
-// offset back of the step's start, which is the same byte of the repeating pattern and always already
-// written.
-// Not HBM-bound: a page is a serial chain and a lone wave issues an instruction every ~17 cycles here
-// (branches, instruction fetch), about 20 MB/s per page; throughput is the number of pages in flight, which
-// LDS sets (20.5 KiB per page: seven per CU, 1792 per chip; 30 GB/s of text at that many pages).  Measured
-// and dropped: buffering the output in the ring and writing it in 16-byte pieces instead of storing each
-// element's bytes (slower: the stores are not what the chain waits for); a 32 KiB ring (fewer pages in
-// flight, and reading far matches back from L2 costs little once no system-wide fence is involved).
-#include <cstdlib>
-
+// "repeat `length` bytes from `offset` back" elements: where an element starts is known only when the one before
+// it has been read, and what a match copies may be what the match before it wrote.  One wave per page breaks both
+// chains, 2 KiB of the stream at a time:
+//   parse   (1) the window lies in LDS, a 32-byte segment per lane.  Every lane reads each place of its segment as
+//               if a sequence (Snappy: one element; LZ4: literals + match) started there, last place first, and notes
+//               where the chain from that place leaves the segment, how many elements it passes and how many bytes
+//               they produce: a place's entry is that of the place its own sequence ends at.
+//           (2) The wave follows the real chain through the window, one look-up per segment entered.
+//           (3) Every lane that was entered walks its segment forward and writes its elements into a list: output
+//               position and source (literal: place in the stream; match: offset).  A sequence that breaks a rule
+//               (offset beyond the output, more output than the page holds, bytes beyond the stream) or needs
+//               bytes that are not staged (a long LZ4 literal in front of its match) ends the window in front of
+//               it; that one sequence is then taken by the wave-uniform code at the end of this file, which
+//               reports a failure the way the formats' decoders do.
+//   execute (4) The window's output is produced a tile of 4 KiB at a time, a lane per byte: the byte's element from
+//               a bit mask of the element starts; a literal byte is fetched; a match byte becomes a pointer to its
+//               source byte (for a match that overlaps itself: to the first period), or is fetched from memory
+//               when the source lies in front of the tile.  Pointers are then followed by all bytes at once
+//               (p = p of p) until every byte has its value: as many rounds as the logarithm of the longest chain
+//               of matches inside the tile.  The tile leaves in aligned 16-byte stores.
+// Not HBM-bound: LDS operations per byte bound it (about ten per output byte).
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
-#include "pqd_lz_common.hpp"
 
 namespace pqd {
 
-// Snappy, 64 input bytes at a time.  Every lane reads the byte at ip + lane as if an element started there
-// (kind, header bytes, lengths, offset) and notes where the element after it would start.  Six rounds of
-// "and from there?" between the lanes give the 2^k-th successor of every position, from which lane i works
-// out the i-th element of the real chain that starts at ip: the elements of the window, in order, one per
-// lane.  A prefix sum of their output lengths places them; literal bytes are then moved by all lanes at
-// once (a lane per input byte), copies one after the other (they may read what the one before wrote), each
-// by the whole wave.  Returns false, with nothing done, when an element of the window breaks a rule
-// (offset 0 or beyond the output, bytes beyond the stream or the page): the caller then takes the
-// one-element-at-a-time path, which reports the failure the way the format's decoder does.
-constexpr uint32_t SW_BAD = 0xFFFFFFFFu, SW_END = 0xFFFFFFFEu;
+#ifndef LW_FAR
+#define LW_FAR 0
+#endif
+#if LW_FAR == 0
+#define LW_FAR_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif LW_FAR == 1
+#define LW_FAR_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define LW_FAR_LOAD(p) (*(p))
+#endif
+constexpr uint32_t LW_WIN = 2048;    // stream bytes per window
+constexpr uint32_t LW_SLACK = 96;    // staged behind it: the headers of sequences that start in the window's last places
+constexpr uint32_t LW_TILE = 4096;   // output bytes per tile
+constexpr uint32_t LW_ELEMS = 1408;  // elements per window at most (Snappy: 2 bytes each; LZ4: 2 per 3 bytes)
+constexpr uint32_t LW_FAIL = 0x80000000u, LW_NONE = 0xFFFFFFFFu, LW_LIT = 0x80000000u;
+constexpr uint32_t LW_HAS = 0x80000000u;  // a tile cell that holds its byte
+#ifndef LW_UNROLL
+#define LW_UNROLL 4u
+#endif
 
-__device__ __forceinline__ bool snappy_window(InStage& in, OutRing& out, uint8_t* marks, uint32_t& ip, uint32_t& op,
-                                              uint32_t in_end, uint32_t cap, uint32_t lane) {
-  const uint32_t p = ip + lane;
-  const uint32_t* st32 = reinterpret_cast<const uint32_t*>(in.lds);
-  const uint32_t w0 = (p & (LZ_STAGE - 1u)) >> 2, sh = (p & 3u) * 8u;
-  const uint32_t d0 = st32[w0], d1 = st32[(w0 + 1u) & (LZ_STAGE / 4u - 1u)], d2 = st32[(w0 + 2u) & (LZ_STAGE / 4u - 1u)];
-  const uint32_t lo = funnel_shr(d0, d1, sh), hi = funnel_shr(d1, d2, sh);  // bytes p .. p+3, p+4 .. p+7
-  const uint32_t tag = lo & 0xFFu, kind = tag & 3u, n6 = tag >> 2;
-  const uint32_t rest = (lo >> 8) | (hi << 24);  // bytes p+1 .. p+4
-  // as a literal
-  const uint32_t nb = n6 >= 60u ? n6 - 59u : 0u;
-  const uint32_t lit_field = nb == 4u ? rest : rest & ((1u << (8u * nb)) - 1u);
-  const uint64_t lit_len = (uint64_t)(nb ? lit_field : n6) + 1u;
-  // as a copy
-  const uint32_t copy_hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
-  const uint32_t copy_len = kind == 1u ? 4u + (n6 & 7u) : 1u + n6;
-  const uint32_t offset = kind == 1u ? ((tag >> 5) << 8) | (rest & 0xFFu) : kind == 2u ? rest & 0xFFFFu : rest;
-  const bool is_lit = kind == 0u;
-  const uint32_t hdr = is_lit ? 1u + nb : copy_hdr;
-  const uint64_t adv64 = is_lit ? hdr + lit_len : hdr;
-  const bool fine = (uint64_t)p + adv64 <= in_end && (is_lit || offset != 0u) && lit_len < (1u << 28);  // (28 bits hold a length below)
-  const uint32_t adv = (uint32_t)adv64;
-  const uint32_t out_len = is_lit ? (uint32_t)lit_len : copy_len;
-  // successor, counted from the window's first byte (a value of 64 or more: outside the window)
-  uint32_t succ[6];
-  succ[0] = (p >= in_end || !fine) ? SW_BAD : p + adv == in_end ? SW_END : lane + adv;  // the stream's end is no position of the chain
-#pragma unroll
-  for (int k = 1; k < 6; ++k) {
-    const uint32_t further = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((succ[k - 1] & 63u) << 2), (int)succ[k - 1]);
-    succ[k] = succ[k - 1] < 64u ? further : succ[k - 1];
+__device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// window byte q in LDS: four bytes of padding behind every 32-byte segment (the lanes' segments start in different banks)
+__device__ __forceinline__ uint32_t lw_at(uint32_t q) { return q + ((q >> 5) << 2); }
+
+struct LwLds {
+  uint8_t win[LW_WIN + LW_SLACK + 4 * ((LW_WIN + LW_SLACK) / 32 + 2)];
+  union {
+    struct {  // parse
+      uint32_t exits[64 * 33];   // where the chain from a place leaves the segment (LW_FAIL: it stops inside)
+      uint32_t produce[64 * 33]; // output bytes of the sequences on the way
+      uint8_t counts[64 * 36];   // elements on the way
+    } p;
+    struct {  // execute
+      uint32_t cell[LW_TILE];
+    } x;
+  } u;
+  uint32_t e_out[LW_ELEMS + 8];  // output position of element i; [n] = where the window's output ends
+  uint32_t e_src[LW_ELEMS + 8];  // LW_LIT | stream position of a literal's first byte, or a match's offset
+};
+
+#ifdef LW_PROF
+#define LW_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); prof[k] += now_ - prof_t; prof_t = now_; }
+#define LW_PROF_ARGS , uint64_t* prof, uint64_t& prof_t
+#define LW_PROF_PASS , prof, prof_t
+#else
+#define LW_STAMP(k)
+#define LW_PROF_ARGS
+#define LW_PROF_PASS
+#endif
+
+struct LwSeq {
+  bool ok;
+  uint32_t next, lit_len, lit_pos, mlen, offset;
+};
+
+// The sequence that would start at stream position p.  Bytes are read from the staged window (positions below
+// `staged`); ok = false: the sequence breaks a rule of the format or needs bytes that are not staged.
+template <int CODEC>
+__device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint32_t p, uint32_t in_end, uint32_t staged) {
+  LwSeq s = {false, 0u, 0u, 0u, 0u, 0u};
+  if (p >= in_end) return s;
+#define LW_B(q) ((uint32_t)win[lw_at((q) - w0)])
+  if (CODEC == PQD_CODEC_SNAPPY) {
+    const uint32_t tag = LW_B(p), kind = tag & 3u, n6 = tag >> 2;
+    const uint32_t b1 = LW_B(p + 1), b2 = LW_B(p + 2), b3 = LW_B(p + 3), b4 = LW_B(p + 4);
+    const uint32_t rest = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
+    if (kind == 0u) {
+      const uint32_t nb = n6 >= 60u ? n6 - 59u : 0u;
+      const uint32_t field = nb == 4u ? rest : rest & ((1u << (8u * nb)) - 1u);
+      const uint64_t len = (uint64_t)(nb ? field : n6) + 1u;
+      const uint64_t end = (uint64_t)p + 1u + nb + len;
+      if (end > in_end) return s;
+      s.lit_len = (uint32_t)len;
+      s.lit_pos = p + 1u + nb;
+      s.next = (uint32_t)end;
+    } else {
+      const uint32_t hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
+      s.mlen = kind == 1u ? 4u + (n6 & 7u) : 1u + n6;
+      s.offset = kind == 1u ? ((tag >> 5) << 8) | b1 : kind == 2u ? rest & 0xFFFFu : rest;
+      if (p + hdr > in_end || s.offset == 0u) return s;
+      s.next = p + hdr;
+    }
+    s.ok = true;
+  } else {
+    const uint32_t token = LW_B(p);
+    uint32_t q = p + 1u, lit = token >> 4;
+    if (lit == 15u) {
+      uint32_t b;
+      do {
+        if (q >= in_end || q >= staged) return s;
+        b = LW_B(q);
+        ++q;
+        lit += b;
+      } while (b == 255u);
+    }
+    if (lit > in_end - q) return s;
+    s.lit_len = lit;
+    s.lit_pos = q;
+    q += lit;
+    if (q == in_end) {  // the last sequence has no match
+      s.next = q;
+      s.ok = true;
+      return s;
+    }
+    if (in_end - q < 2u || q + 2u > staged) return s;
+    s.offset = LW_B(q) | (LW_B(q + 1) << 8);
+    q += 2u;
+    uint32_t m = token & 15u;
+    if (m == 15u) {
+      uint32_t b;
+      do {
+        if (q >= in_end || q >= staged) return s;
+        b = LW_B(q);
+        ++q;
+        m += b;
+      } while (b == 255u);
+    }
+    if (s.offset == 0u) return s;
+    s.mlen = m + 4u;
+    s.next = q;
+    s.ok = true;
   }
-  // lane i: the i-th element of the chain from position 0
-  uint32_t pos = 0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const uint32_t hop = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((pos & 63u) << 2), (int)succ[k]);
-    if ((lane >> k) & 1u) pos = pos < 64u ? hop : pos;
+#undef LW_B
+  return s;
+}
+
+// One window: the sequences from stream position ip on, as far as the window (or the chain of well-formed
+// sequences) goes; their output is written.  ip / op move behind them.  Returns true when the chain stopped in
+// front of a sequence that the caller has to take by itself.
+template <int CODEC>
+__device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op,
+                                          uint32_t in_end, uint32_t cap, uint32_t lane LW_PROF_ARGS) {
+  const uint32_t w0 = ip;
+  const uint32_t staged = in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
+  // ---- the window -> LDS
+  __syncthreads();  // (one wave: an order for the LDS accesses)
+  for (uint32_t t = lane * 16u; t < staged - w0; t += 1024u) {
+    if (t + 16u <= staged - w0) {
+      u32x4 v;
+      __builtin_memcpy(&v, (const uint8_t*)(src + w0 + t), 16);
+      uint32_t* d = reinterpret_cast<uint32_t*>(L.win + lw_at(t));  // (a piece never crosses a segment's end)
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    } else {
+      for (uint32_t k = 0; t + k < staged - w0; ++k) L.win[lw_at(t + k)] = src[w0 + t + k];
+    }
   }
-  const uint64_t inside = __builtin_amdgcn_ballot_w64(pos < 64u);  // lanes 0 .. T-1 (positions grow with i)
-  const uint32_t T = (uint32_t)__builtin_popcountll(inside);         // at most 32: an element is two bytes or more
-  const uint32_t leave = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)T);  // where the chain leaves the window
-  if (leave == SW_BAD) return false;
-  const bool mine = lane < T;
-  // the elements' fields, gathered from the lanes that parsed them
-  const uint32_t src_lane = (pos & 63u) << 2;
-  const uint32_t e_meta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane, (int)(out_len | (hdr << 28) | (is_lit ? 0x80000000u : 0u)));
-  const uint32_t e_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src_lane, (int)offset);
-  const uint32_t e_out = mine ? e_meta & 0x0FFFFFFFu : 0u;  // (a literal of 2^28 bytes or more does not fit the stream: `fine` saw to it)
-  const bool e_lit = (e_meta >> 31) != 0;
-  const uint32_t inc = wave_scan_inclusive(e_out);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-  const uint32_t e_op = op + inc - e_out;  // where the element's output starts
-  if ((uint64_t)op + total > cap) return false;
-  if (__builtin_amdgcn_ballot_w64(mine && !e_lit && e_off > e_op)) return false;
-  // ---- literal bytes, a lane per input byte: the element a byte belongs to is the last one that starts at
-  // or before it
   __syncthreads();
-  marks[lane] = 0;
+  LW_STAMP(0)
+  // ---- 1. the places of this lane's segment, last to first
+  const uint32_t seg = w0 + lane * 32u;
+  for (int pl = 31; pl >= 0; --pl) {
+    const LwSeq s = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)pl, in_end, staged);
+    uint32_t ex = LW_FAIL, c = 0, made = 0;
+    if (s.ok) {
+      ex = s.next;
+      c = (s.lit_len ? 1u : 0u) + (s.mlen ? 1u : 0u);
+      made = s.lit_len + s.mlen;
+      if (s.next < seg + 32u) {
+        const uint32_t j = s.next - seg;
+        ex = L.u.p.exits[lane * 33u + j];
+        c += L.u.p.counts[lane * 36u + j];
+        made += L.u.p.produce[lane * 33u + j];
+      }
+    }
+    L.u.p.exits[lane * 33u + (uint32_t)pl] = ex;
+    L.u.p.counts[lane * 36u + (uint32_t)pl] = (uint8_t)c;
+    L.u.p.produce[lane * 33u + (uint32_t)pl] = made;
+  }
   __syncthreads();
-  if (mine) marks[pos] = 1;
-  __syncthreads();
-  const uint64_t starts = __builtin_amdgcn_ballot_w64(marks[lane] != 0);
-  const uint32_t rank = (uint32_t)__builtin_popcountll(starts & ((2ull << lane) - 1ull)) - 1u;  // lane 0 starts an element
-  const uint32_t o_pos = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)pos);
-  const uint32_t o_meta = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)e_meta);
-  const uint32_t o_op = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rank << 2), (int)e_op);
+  LW_STAMP(1)
+  // ---- 2. the chain through the window
+  uint32_t entry = LW_NONE, first_elem = 0;
+  uint64_t first_out = 0;
   {
-    const uint32_t first = o_pos + ((o_meta >> 28) & 7u);  // the literal's first byte
-    if ((o_meta >> 31) && lane >= first && lane - first < (o_meta & 0x0FFFFFFFu)) {
-      const uint8_t v = (uint8_t)in.byte(p);
-      const uint32_t at = o_op + (lane - first);
-      out.ring[at & out.ring_mask] = v;
-      out.dst[at] = v;
+    uint32_t at = ip, elems = 0;
+    uint64_t made = op;
+    while (at < w0 + LW_WIN && at < in_end && made <= cap) {
+      const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
+      const uint32_t ex = lw_uni(L.u.p.exits[k * 33u + pl]), c = lw_uni(L.u.p.counts[k * 36u + pl]);
+      const uint32_t m = lw_uni(L.u.p.produce[k * 33u + pl]);
+      if (lane == k) {
+        entry = at;
+        first_elem = elems;
+        first_out = made;
+      }
+      elems += c;
+      made += m;
+      if (ex & LW_FAIL) break;
+      at = ex;
     }
   }
-  // a literal that goes on behind the window (always the window's last element): what is left of it is moved
-  // AFTER the copies, whose ring slots it may take
-  uint32_t tail_from = 0, tail_op = 0, tail_len = 0;
-  if (T) {
-    const uint32_t l_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)(T - 1u));
-    const uint32_t l_meta = (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)(T - 1u));
-    const uint32_t l_op = (uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)(T - 1u));
-    const uint32_t first = l_pos + ((l_meta >> 28) & 7u), len = l_meta & 0x0FFFFFFFu;
-    if ((l_meta >> 31) && first + len > 64u) {
-      const uint32_t done = first < 64u ? 64u - first : 0u;  // bytes moved above
-      tail_from = first < 64u ? 64u : first;                 // window position of the next one
-      tail_op = l_op + done;
-      tail_len = len - done;
+  __syncthreads();  // the tables are done with: their room becomes the tile
+  LW_STAMP(2)
+  // ---- 3. this lane's elements
+  uint32_t mine = 0, end = 0;
+  uint64_t out_end = 0;
+  bool stop = false;
+  if (entry != LW_NONE) {
+    uint32_t q = entry, i = first_elem;
+    uint64_t o = first_out;
+    while (q < seg + 32u && q < in_end) {
+      const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
+      if (!s.ok || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
+        stop = true;
+        break;
+      }
+      if (s.lit_len) {
+        L.e_out[i] = (uint32_t)o;
+        L.e_src[i] = LW_LIT | s.lit_pos;
+        o += s.lit_len;
+        ++i;
+      }
+      if (s.mlen) {
+        L.e_out[i] = (uint32_t)o;
+        L.e_src[i] = s.offset;
+        o += s.mlen;
+        ++i;
+      }
+      q = s.next;
+    }
+    mine = i - first_elem;
+    end = q;
+    out_end = o;
+  }
+  // lanes behind one that stopped were entered for nothing
+  const uint64_t stops = __builtin_amdgcn_ballot_w64(stop);
+  if (stops && lane > (uint32_t)__builtin_ctzll(stops)) {
+    entry = LW_NONE;
+    mine = 0;
+  }
+  const uint64_t entered = __builtin_amdgcn_ballot_w64(entry != LW_NONE);
+  const uint32_t n_elems = lw_uni((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(mine), 63));
+  if (!entered) return true;  // (cannot be: ip lies in the window)
+  const uint32_t last = lw_uni(63u - (uint32_t)__builtin_clzll(entered));
+  const uint32_t new_ip = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)last);
+  const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)out_end, (int)last);  // (at most cap)
+  const bool stopped = stops != 0;
+  if (lane == 0) L.e_out[n_elems] = o1;
+  __syncthreads();
+  LW_STAMP(3)
+  // ---- 4. the output, tile by tile
+  const uint32_t o0 = op;
+  uint32_t e_lo = 0;  // elements below e_lo start at or in front of the tile
+  for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
+    const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
+    // element starts inside (tb, te): lane t holds the mask of bytes [64 t, 64 t + 64) of the tile
+    uint64_t starts = 0;
+    {
+      // (a lane per element; the masks are gathered through LDS words that the tile's pointers overwrite later)
+      uint32_t* words = L.u.x.cell;
+      words[lane] = 0;
+      words[lane + 64u] = 0;
+      __syncthreads();
+      // the element that holds byte tb: the last one that starts at or in front of it
+      for (;;) {
+        const uint32_t i = e_lo + lane;
+        const bool in_front = i < n_elems && L.e_out[i] <= tb;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
+        e_lo += (uint32_t)__builtin_popcountll(m);
+        if (m != ~0ull) break;
+      }
+      for (uint32_t b = e_lo;; b += 64u) {
+        const uint32_t i = b + lane;
+        const uint32_t eo = i < n_elems ? L.e_out[i] : 0xFFFFFFFFu;
+        const bool inside = eo < te;
+        if (inside) atomicOr(&words[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
+        if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
+      }
+      __syncthreads();
+      starts = (uint64_t)words[2u * lane] | ((uint64_t)words[2u * lane + 1u] << 32);
+      __syncthreads();
+    }
+    LW_STAMP(4)
+    const uint32_t in_seg = (uint32_t)__builtin_popcountll(starts);
+    const uint32_t before = wave_scan_inclusive(in_seg) - in_seg;
+    const uint32_t a = (uint32_t)((uintptr_t)(dst + tb) & 15u);
+    const uint64_t upto = (2ull << lane) - 1ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles before this one are in memory
+    // a word per byte of the tile: LW_HAS | the byte, or the tile position of the byte it repeats
+    uint32_t* cell = L.u.x.cell;
+    const uint32_t n_steps = (te - tb + 63u) >> 6;
+    bool open = false;
+    for (uint32_t t0 = 0; t0 < n_steps; t0 += LW_UNROLL) {
+      uint32_t eo[LW_UNROLL], es[LW_UNROLL], word[LW_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+        const uint32_t t = t0 + u < n_steps ? t0 + u : n_steps - 1u;
+        const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)starts, (int)t);
+        const uint32_t s_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(starts >> 32), (int)t);
+        const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)before, (int)t);
+        uint32_t i = e_lo - 1u + bf + (uint32_t)__builtin_popcountll((((uint64_t)s_hi << 32) | s_lo) & upto);
+        i = i < n_elems ? i : n_elems - 1u;  // (bytes behind the output's end: any element, the result is not used)
+        eo[u] = L.e_out[i];
+        es[u] = L.e_src[i];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+        const uint32_t o = tb + (t0 + u) * 64u + lane;
+        const uint32_t rel = o - eo[u];
+        word[u] = LW_HAS;
+        if (t0 + u < n_steps && o < te) {
+          if (es[u] & LW_LIT) {
+            const uint32_t at = (es[u] & ~LW_LIT) + rel;
+            word[u] = LW_HAS | (at < staged ? (uint32_t)L.win[lw_at(at - w0)] : (uint32_t)src[at]);
+          } else {
+            uint32_t from = o - es[u];
+            if (rel >= es[u]) from = eo[u] - es[u] + rel % es[u];  // a match that repeats itself: the first period
+            if (from < tb) {
+              word[u] = LW_HAS | (uint32_t)LW_FAR_LOAD(dst + from);  // (written by this wave: read where the stores went)
+            } else {
+              word[u] = from - tb;
+              open = true;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < LW_UNROLL; ++u)
+        if (t0 + u < n_steps) cell[(t0 + u) * 64u + lane] = word[u];
+    }
+    __syncthreads();
+    LW_STAMP(5)
+    // every byte follows its pointer until it arrives at a byte that has its value
+    while (__builtin_amdgcn_ballot_w64(open)) {
+      open = false;
+      for (uint32_t t0 = 0; t0 < n_steps; t0 += LW_UNROLL) {
+        uint32_t mine_[LW_UNROLL], other[LW_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
+#pragma unroll
+        for (uint32_t u = 0; u < LW_UNROLL; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
+#pragma unroll
+        for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+          if (!(mine_[u] & LW_HAS)) {
+            cell[(t0 + u) * 64u + lane] = other[u];  // its value, or the byte that one repeats
+            open = open || !(other[u] & LW_HAS);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    LW_STAMP(6)
+    // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
+    {
+      PQD_GLOBAL uint8_t* gbase = dst + tb - a;  // 16-byte aligned
+      const uint32_t stop_at = a + (te - tb);
+      for (uint32_t t = lane * 16u; t < stop_at; t += 1024u) {
+        // the bytes of tile positions t - a .. t - a + 15
+        uint32_t packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+          const uint32_t q = t + k - a;  // (wraps below a: not used then)
+          const uint32_t v = (t + k >= a && t + k < stop_at) ? cell[q] & 0xFFu : 0u;
+          packed[k >> 2] |= v << (8u * (k & 3u));
+        }
+        if (t >= a && t + 16u <= stop_at) {
+          const u32x4 v = {packed[0], packed[1], packed[2], packed[3]};
+          *(PQD_GLOBAL u32x4*)(gbase + t) = v;
+        } else {
+          for (uint32_t k = 0; k < 16u; ++k)
+            if (t + k >= a && t + k < stop_at) gbase[t + k] = (uint8_t)(packed[k >> 2] >> (8u * (k & 3u)));
+        }
+      }
+    }
+    __syncthreads();
+    LW_STAMP(7)
+  }
+  op = o1;
+  ip = new_ip;
+  return stopped;
+}
+
+// ---- one sequence, wave-uniformly, with its bytes moved from memory to memory: the sequences the windows stop at
+__device__ __forceinline__ uint32_t lw_byte(const PQD_GLOBAL uint8_t* src, uint32_t pos) { return lw_uni(src[pos]); }
+
+__device__ __forceinline__ void lw_copy_literal(const PQD_GLOBAL uint8_t* from, PQD_GLOBAL uint8_t* to, uint32_t len, uint32_t lane) {
+  for (uint32_t i = lane; i < len; i += 64u) to[i] = from[i];
+}
+
+// `len` bytes from `offset` back; lane l of a step takes the byte (l mod offset) - offset back of the step's start for
+// offsets below 64: the same byte of the repeating pattern, and one that is already written
+__device__ __forceinline__ void lw_copy_match(PQD_GLOBAL uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, uint32_t lane) {
+  uint32_t lm = lane;
+  if (offset < 64u) {
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+      const uint32_t t = offset << k;
+      lm = lm >= t ? lm - t : lm;
     }
   }
-  // ---- copies, in order.  The window's literal bytes are in the ring already, up to output position
-  // op + total - tail_len: a copy whose source slots lie a whole ring below a position written above reads
-  // its bytes back from memory instead (the slot of source byte s holds s + ring size by now).
-  const uint32_t written_end = op + total - tail_len;
-  uint64_t copies = __builtin_amdgcn_ballot_w64(mine && !e_lit);
-  while (copies) {
-    const uint32_t i = (uint32_t)__builtin_ctzll(copies);
-    copies &= copies - 1ull;
-    const uint32_t c_op = (uint32_t)__builtin_amdgcn_readlane((int)e_op, (int)i);
-    const uint32_t c_off = (uint32_t)__builtin_amdgcn_readlane((int)e_off, (int)i);
-    out.match(c_op, c_off, (uint32_t)__builtin_amdgcn_readlane((int)e_meta, (int)i) & 0x0FFFFFFFu,
-              c_off + (written_end - c_op) > out.ring_mask + 1u);
+  // the bytes were stored by this wave: its stores are waited for, and the loads read where the stores went
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t b = 0; b < len; b += 64u) {
+    if (len > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a match that reads its own output
+    if (b + lane < len) dst[op + b + lane] = __hip_atomic_load(dst + (op + b + lm - offset), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tail_len) out.literal(in, ip + tail_from, tail_op, tail_len, 1900u);  // (ip + 64 + 1900 lies inside the staged chunks)
-  op += total;
-  ip = leave == SW_END ? in_end : ip + leave;
+}
+
+// false: the sequence breaks a rule (nothing of it is written; ip / op stay in front of it... LZ4: behind the literals
+// already moved, as the format's decoders leave them)
+template <int CODEC>
+__device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op, uint32_t in_end,
+                                       uint32_t cap, uint32_t lane) {
+  if (CODEC == PQD_CODEC_SNAPPY) {
+    const uint32_t tag = lw_byte(src, ip), left = in_end - ip, kind = tag & 3u;
+    if (kind == 0u) {
+      uint64_t l = tag >> 2;
+      uint32_t hdr = 1;
+      if (l >= 60u) {
+        const uint32_t nb = (uint32_t)l - 59u;
+        if (left < 1u + nb) return false;
+        l = 0;
+        for (uint32_t k = 0; k < nb; ++k) l |= (uint64_t)lw_byte(src, ip + 1u + k) << (8u * k);
+        hdr = 1u + nb;
+      }
+      const uint64_t len = l + 1u;
+      if (len > left - hdr || len > cap - op) return false;
+      lw_copy_literal(src + ip + hdr, dst + op, (uint32_t)len, lane);
+      op += (uint32_t)len;
+      ip += hdr + (uint32_t)len;
+    } else {
+      const uint32_t hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
+      if (left < hdr) return false;
+      uint32_t rest = 0;
+      for (uint32_t k = 1; k < hdr; ++k) rest |= lw_byte(src, ip + k) << (8u * (k - 1u));
+      const uint32_t len = kind == 1u ? 4u + ((tag >> 2) & 7u) : 1u + (tag >> 2);
+      const uint32_t offset = kind == 1u ? ((tag >> 5) << 8) | (rest & 0xFFu) : rest;
+      if (offset == 0u || offset > op || len > cap - op) return false;
+      lw_copy_match(dst, op, offset, len, lane);
+      op += len;
+      ip += hdr;
+    }
+    return true;
+  }
+  const uint32_t token = lw_byte(src, ip);
+  ++ip;
+  uint64_t lit = token >> 4;
+  if (lit == 15u) {
+    uint32_t b;
+    do {
+      if (ip >= in_end) return false;
+      b = lw_byte(src, ip);
+      ++ip;
+      lit += b;
+    } while (b == 255u);
+  }
+  if (lit > in_end - ip || lit > cap - op) return false;
+  lw_copy_literal(src + ip, dst + op, (uint32_t)lit, lane);
+  op += (uint32_t)lit;
+  ip += (uint32_t)lit;
+  if (ip == in_end) return true;  // the last sequence has no match
+  if (in_end - ip < 2u) return false;
+  const uint32_t offset = lw_byte(src, ip) | (lw_byte(src, ip + 1u) << 8);
+  ip += 2u;
+  uint64_t mlen = token & 15u;
+  if (mlen == 15u) {
+    uint32_t b;
+    do {
+      if (ip >= in_end) return false;
+      b = lw_byte(src, ip);
+      ++ip;
+      mlen += b;
+    } while (b == 255u);
+  }
+  mlen += 4u;
+  if (offset == 0u || offset > op || mlen > cap - op) return false;
+  lw_copy_match(dst, op, offset, (uint32_t)mlen, lane);
+  op += (uint32_t)mlen;
   return true;
 }
 
-template <int CODEC, uint32_t RING>
+template <int CODEC>
 __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
                                                  pqd_page_result* __restrict__ results, uint32_t n_pages) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
-  __shared__ uint8_t s_marks[64];
+  __shared__ LwLds L;
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
@@ -168,28 +521,18 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     }
     return;
   }
-  InStage in;
-  in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
-  const uint32_t skew = (uint32_t)((uintptr_t)d.src & 15u);
-  in.end = skew + d.src_len;
-  in.lane = lane;
-  in.lds = s_stage;
-  in.cur = 0;
-  in.start(0);
-  in.win_at = 0x80000000u;  // nothing in the window yet
-  in.win0 = in.win1 = 0;
-  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane, RING - 1u};
-  const uint32_t cap = d.dst_len, in_end = in.end;
-  uint32_t ip = skew, op = 0;
+  const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.src;
+  PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)d.dst;
+  const uint32_t cap = d.dst_len, in_end = d.src_len;
+  uint32_t ip = 0, op = 0;
   int32_t status = PQD_OK;
-
+  uint64_t ulen = 0;
   if (CODEC == PQD_CODEC_SNAPPY) {
     // preamble: the uncompressed length as a varint32
-    uint64_t ulen = 0;
     uint32_t shift = 0;
     bool ok = false;
     while (ip < in_end && shift <= 28u) {
-      const uint32_t b = (uint32_t)in.peek8(ip) & 0xFFu;
+      const uint32_t b = lw_byte(src, ip);
       ++ip;
       ulen |= (uint64_t)(b & 0x7Fu) << shift;
       if (!(b & 0x80u)) {
@@ -200,131 +543,34 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     }
     if (!ok || ulen > 0xFFFFFFFFull) {
       status = PQD_DECODE;
-      ip = skew;
-    } else {
-      bool one_by_one = false;  // set when a window met something out of order: the rest of the page goes this way
-      while (ip < in_end) {
-        in.reach(ip);
-        if (!one_by_one) {
-          if (snappy_window(in, out, s_marks, ip, op, in_end, cap, lane)) continue;
-          one_by_one = true;
-        }
-        const uint64_t head = in.peek8(ip);
-        const uint32_t tag = (uint32_t)head & 0xFFu;
-        const uint32_t rest = (uint32_t)(head >> 8);
-        const uint32_t left = in_end - ip;
-        const uint32_t kind = tag & 3u;
-        if (kind == 0u) {
-          uint64_t l = tag >> 2;
-          uint32_t hdr = 1;
-          if (l >= 60u) {
-            const uint32_t nb = (uint32_t)l - 59u;
-            if (left < 1u + nb) {
-              status = PQD_DECODE;
-              break;
-            }
-            l = nb == 4u ? rest : (rest & ((1u << (8u * nb)) - 1u));
-            hdr = 1u + nb;
-          }
-          const uint64_t len = l + 1u;
-          if (len > left - hdr || len > cap - op) {
-            status = PQD_DECODE;
-            break;
-          }
-          out.literal(in, ip + hdr, op, (uint32_t)len);
-          op += (uint32_t)len;
-          ip += hdr + (uint32_t)len;
-        } else {
-          uint32_t hdr, len, offset;
-          if (kind == 1u) {
-            hdr = 2;
-            len = 4u + ((tag >> 2) & 7u);
-            offset = ((tag >> 5) << 8) | (rest & 0xFFu);
-          } else if (kind == 2u) {
-            hdr = 3;
-            len = 1u + (tag >> 2);
-            offset = rest & 0xFFFFu;
-          } else {
-            hdr = 5;
-            len = 1u + (tag >> 2);
-            offset = rest;
-          }
-          if (left < hdr || offset == 0u || offset > op || len > cap - op) {
-            status = PQD_DECODE;
-            break;
-          }
-          out.match(op, offset, len);
-          op += len;
-          ip += hdr;
-        }
-      }
-      // the stream produces what its preamble announced, and the page what its header announced
-      if (status == PQD_OK && (op != ulen || op != cap)) status = PQD_DECODE;
+      ip = 0;
     }
-  } else {  // LZ4 block
+  }
+#ifdef LW_PROF
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_readcyclecounter();
+#endif
+  if (status == PQD_OK) {
     while (ip < in_end) {
-      in.reach(ip);
-      const uint32_t token = (uint32_t)in.peek8(ip) & 0xFFu;
-      ++ip;
-      uint64_t lit = token >> 4;
-      bool bad = false;
-      if (lit == 15u) {
-        uint32_t b;
-        do {
-          if (ip >= in_end) {
-            bad = true;
-            break;
-          }
-          in.reach(ip);
-          b = (uint32_t)in.peek8(ip) & 0xFFu;
-          ++ip;
-          lit += b;
-        } while (b == 255u);
-      }
-      if (bad || lit > in_end - ip || lit > cap - op) {
+      if (!lw_window<CODEC>(L, src, dst, ip, op, in_end, cap, lane LW_PROF_PASS)) continue;
+      if (ip >= in_end) break;
+      if (!lw_one<CODEC>(src, dst, ip, op, in_end, cap, lane)) {
         status = PQD_DECODE;
         break;
       }
-      in.reach(ip);
-      out.literal(in, ip, op, (uint32_t)lit);
-      op += (uint32_t)lit;
-      ip += (uint32_t)lit;
-      if (ip == in_end) break;  // the last sequence has no match
-      if (in_end - ip < 2u) {
-        status = PQD_DECODE;
-        break;
-      }
-      in.reach(ip);
-      const uint32_t offset = (uint32_t)in.peek8(ip) & 0xFFFFu;
-      ip += 2u;
-      uint64_t mlen = token & 15u;
-      if (mlen == 15u) {
-        uint32_t b;
-        do {
-          if (ip >= in_end) {
-            bad = true;
-            break;
-          }
-          in.reach(ip);
-          b = (uint32_t)in.peek8(ip) & 0xFFu;
-          ++ip;
-          mlen += b;
-        } while (b == 255u);
-      }
-      mlen += 4u;
-      if (bad || offset == 0u || offset > op || mlen > cap - op) {
-        status = PQD_DECODE;
-        break;
-      }
-      out.match(op, offset, (uint32_t)mlen);
-      op += (uint32_t)mlen;
     }
-    if (status == PQD_OK && op != cap) status = PQD_DECODE;  // the page header announced cap bytes
+    // the stream produces what its preamble announced (Snappy), and the page what its header announced
+    if (status == PQD_OK && ((CODEC == PQD_CODEC_SNAPPY && op != ulen) || op != cap)) status = PQD_DECODE;
   }
   if (lane == 0) {
-    pqd_page_result r = {status, op, ip - skew, 0u};
+    pqd_page_result r = {status, op, ip, 0u};
     results[page] = r;
   }
+#ifdef LW_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && cap >= 64u)
+    for (int k = 0; k < 8; ++k) reinterpret_cast<PQD_GLOBAL uint64_t*>(dst)[k] = prof[k];
+#endif
 }
 
 // stored bytes (an uncompressed codec, the level bytes of a V2 page, a V2 page with is_compressed = false)
@@ -357,12 +603,11 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
   }
 }
 
-template <uint32_t RING>
 static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
   if (codec == PQD_CODEC_SNAPPY)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
   else if (codec == PQD_CODEC_LZ4_RAW)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
 }
 
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
@@ -374,14 +619,7 @@ hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_re
     hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
     return hipGetLastError();
   }
-  const char* v = getenv("PQD_LZ_RING");
-  const uint32_t ring = v ? (uint32_t)atoi(v) * 1024u : LZ_RING_DEFAULT;
-  if (ring == 8192u)
-    launch_lz<8192u>(descs, results, n_pages, codec, stream);
-  else if (ring == 32768u)
-    launch_lz<32768u>(descs, results, n_pages, codec, stream);
-  else
-    launch_lz<16384u>(descs, results, n_pages, codec, stream);
+  launch_lz(descs, results, n_pages, codec, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
