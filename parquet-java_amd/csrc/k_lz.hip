@@ -6,8 +6,9 @@
 // 27-35) and Lz4RawDecompressor.uncompress -> io.airlift.compress.lz4.Lz4Decompressor (codec/
 // Lz4RawDecompressor.java:29-49).  Both formats are a byte-serial stream of "copy these literal bytes" and
 // "repeat `length` bytes from `offset` back" elements: where an element starts is known only when the one before
-// it has been read, and what a match copies may be what the match before it wrote.  One wave per page breaks both
-// chains, 2 KiB of the stream at a time:
+// it has been read, and what a match copies may be what the match before it wrote.  A workgroup of four waves per
+// page breaks both chains, 2 KiB of the stream at a time (the parse is the first wave's; the bytes of the output
+// tiles are shared out among all four):
 //   parse   (1) the window lies in LDS, a 32-byte segment per lane.  Every lane reads each place of its segment as
 //               if a sequence (Snappy: one element; LZ4: literals + match) started there, last place first, and notes
 //               where the chain from that place leaves the segment, how many elements it passes and how many bytes
@@ -25,7 +26,11 @@
 //               when the source lies in front of the tile.  Pointers are then followed by all bytes at once
 //               (p = p of p) until every byte has its value: as many rounds as the logarithm of the longest chain
 //               of matches inside the tile.  The tile leaves in aligned 16-byte stores.
-// Not HBM-bound: LDS operations per byte bound it (about ten per output byte).
+// Not HBM-bound: instructions per byte bound it (a lone wave per SIMD issues one every four to five cycles; a byte of
+// repetitive text costs about twenty wave-instructions over its 64 lanes, half of them in the pointer rounds).
+// Measured and dropped: an element per lane copying its bytes in order, with an LDS ring of the last 32 KiB of output
+// (fewer instructions when matches reach far back, three times slower when most matches read what the 64 elements
+// of their own batch write, as in columns of small numbers and repetitive text).
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 
@@ -43,12 +48,16 @@ namespace pqd {
 #endif
 constexpr uint32_t LW_WIN = 2048;    // stream bytes per window
 constexpr uint32_t LW_SLACK = 96;    // staged behind it: the headers of sequences that start in the window's last places
+constexpr uint32_t LW_LENGTH_BYTES = 4;  // LZ4 length bytes read per length in the windows
 constexpr uint32_t LW_TILE = 4096;   // output bytes per tile
 constexpr uint32_t LW_ELEMS = 1408;  // elements per window at most (Snappy: 2 bytes each; LZ4: 2 per 3 bytes)
 constexpr uint32_t LW_FAIL = 0x80000000u, LW_NONE = 0xFFFFFFFFu, LW_LIT = 0x80000000u;
 constexpr uint32_t LW_HAS = 0x80000000u;  // a tile cell that holds its byte
 #ifndef LW_UNROLL
 #define LW_UNROLL 4u
+#endif
+#ifndef LW_WAVES
+#define LW_WAVES 4u  // waves per page
 #endif
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -69,6 +78,10 @@ struct LwLds {
   } u;
   uint32_t e_out[LW_ELEMS + 8];  // output position of element i; [n] = where the window's output ends
   uint32_t e_src[LW_ELEMS + 8];  // LW_LIT | stream position of a literal's first byte, or a match's offset
+  uint32_t t_lo[64], t_hi[64];   // per 64 bytes of the tile: the bytes at which an element starts
+  uint32_t t_before[64];         // the element that holds the byte in front of those 64
+  uint32_t n_elems, new_ip, out_end, e_lo, flag[3];  // what the first wave tells the others
+  bool stopped;
 };
 
 #ifdef LW_PROF
@@ -118,9 +131,11 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
     const uint32_t token = LW_B(p);
     uint32_t q = p + 1u, lit = token >> 4;
     if (lit == 15u) {
-      uint32_t b;
+      // (a length of more than LW_LENGTH_BYTES bytes: a sequence for the wave-uniform code, which reads them 64 at a
+      // time; a run of 255s in the stream would otherwise be walked from every place in it)
+      uint32_t b, k = 0;
       do {
-        if (q >= in_end || q >= staged) return s;
+        if (q >= in_end || q >= staged || ++k > LW_LENGTH_BYTES) return s;
         b = LW_B(q);
         ++q;
         lit += b;
@@ -140,9 +155,9 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
     q += 2u;
     uint32_t m = token & 15u;
     if (m == 15u) {
-      uint32_t b;
+      uint32_t b, k = 0;
       do {
-        if (q >= in_end || q >= staged) return s;
+        if (q >= in_end || q >= staged || ++k > LW_LENGTH_BYTES) return s;
         b = LW_B(q);
         ++q;
         m += b;
@@ -159,15 +174,17 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
 
 // One window: the sequences from stream position ip on, as far as the window (or the chain of well-formed
 // sequences) goes; their output is written.  ip / op move behind them.  Returns true when the chain stopped in
-// front of a sequence that the caller has to take by itself.
+// front of a sequence that the caller has to take by itself.  All LW_WAVES waves of the workgroup call it: the parse
+// is the first wave's, the tiles' bytes are shared out among all of them.
 template <int CODEC>
 __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op,
-                                          uint32_t in_end, uint32_t cap, uint32_t lane LW_PROF_ARGS) {
+                                          uint32_t in_end, uint32_t cap, uint32_t tid LW_PROF_ARGS) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t w0 = ip;
   const uint32_t staged = in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
   // ---- the window -> LDS
-  __syncthreads();  // (one wave: an order for the LDS accesses)
-  for (uint32_t t = lane * 16u; t < staged - w0; t += 1024u) {
+  __syncthreads();
+  for (uint32_t t = tid * 16u; t < staged - w0; t += LW_WAVES * 1024u) {
     if (t + 16u <= staged - w0) {
       u32x4 v;
       __builtin_memcpy(&v, (const uint8_t*)(src + w0 + t), 16);
@@ -182,112 +199,119 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
   }
   __syncthreads();
   LW_STAMP(0)
-  // ---- 1. the places of this lane's segment, last to first
-  const uint32_t seg = w0 + lane * 32u;
-  for (int pl = 31; pl >= 0; --pl) {
-    const LwSeq s = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)pl, in_end, staged);
-    uint32_t ex = LW_FAIL, c = 0, made = 0;
-    if (s.ok) {
-      ex = s.next;
-      c = (s.lit_len ? 1u : 0u) + (s.mlen ? 1u : 0u);
-      made = s.lit_len + s.mlen;
-      if (s.next < seg + 32u) {
-        const uint32_t j = s.next - seg;
-        ex = L.u.p.exits[lane * 33u + j];
-        c += L.u.p.counts[lane * 36u + j];
-        made += L.u.p.produce[lane * 33u + j];
+  if (wave == 0) {
+    // ---- 1. the places of this lane's segment, last to first
+    const uint32_t seg = w0 + lane * 32u;
+    for (int pl = 31; pl >= 0; --pl) {
+      const LwSeq s = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)pl, in_end, staged);
+      uint32_t ex = LW_FAIL, c = 0, made = 0;
+      if (s.ok) {
+        ex = s.next;
+        c = (s.lit_len ? 1u : 0u) + (s.mlen ? 1u : 0u);
+        made = s.lit_len + s.mlen;
+        if (s.next < seg + 32u) {
+          const uint32_t j = s.next - seg;
+          ex = L.u.p.exits[lane * 33u + j];
+          c += L.u.p.counts[lane * 36u + j];
+          made += L.u.p.produce[lane * 33u + j];
+        }
+      }
+      L.u.p.exits[lane * 33u + (uint32_t)pl] = ex;
+      L.u.p.counts[lane * 36u + (uint32_t)pl] = (uint8_t)c;
+      L.u.p.produce[lane * 33u + (uint32_t)pl] = made;
+    }
+    __builtin_amdgcn_wave_barrier();
+    LW_STAMP(1)
+    // ---- 2. the chain through the window
+    uint32_t entry = LW_NONE, first_elem = 0;
+    uint64_t first_out = 0;
+    {
+      uint32_t at = ip, elems = 0;
+      uint64_t made = op;
+      while (at < w0 + LW_WIN && at < in_end && made <= cap) {
+        const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
+        const uint32_t ex = lw_uni(L.u.p.exits[k * 33u + pl]), c = lw_uni(L.u.p.counts[k * 36u + pl]);
+        const uint32_t m = lw_uni(L.u.p.produce[k * 33u + pl]);
+        if (lane == k) {
+          entry = at;
+          first_elem = elems;
+          first_out = made;
+        }
+        elems += c;
+        made += m;
+        if (ex & LW_FAIL) break;
+        at = ex;
       }
     }
-    L.u.p.exits[lane * 33u + (uint32_t)pl] = ex;
-    L.u.p.counts[lane * 36u + (uint32_t)pl] = (uint8_t)c;
-    L.u.p.produce[lane * 33u + (uint32_t)pl] = made;
+    LW_STAMP(2)
+    // ---- 3. this lane's elements
+    uint32_t mine = 0, end = 0;
+    uint64_t out_end = 0;
+    bool stop = false;
+    if (entry != LW_NONE) {
+      uint32_t q = entry, i = first_elem;
+      uint64_t o = first_out;
+      while (q < seg + 32u && q < in_end) {
+        const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
+        if (!s.ok || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
+          stop = true;
+          break;
+        }
+        if (s.lit_len) {
+          L.e_out[i] = (uint32_t)o;
+          L.e_src[i] = LW_LIT | s.lit_pos;
+          o += s.lit_len;
+          ++i;
+        }
+        if (s.mlen) {
+          L.e_out[i] = (uint32_t)o;
+          L.e_src[i] = s.offset;
+          o += s.mlen;
+          ++i;
+        }
+        q = s.next;
+      }
+      mine = i - first_elem;
+      end = q;
+      out_end = o;
+    }
+    // lanes behind one that stopped were entered for nothing
+    const uint64_t stops = __builtin_amdgcn_ballot_w64(stop);
+    if (stops && lane > (uint32_t)__builtin_ctzll(stops)) {
+      entry = LW_NONE;
+      mine = 0;
+    }
+    const uint64_t entered = __builtin_amdgcn_ballot_w64(entry != LW_NONE);
+    const uint32_t n = lw_uni((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(mine), 63));
+    const uint32_t last = entered ? lw_uni(63u - (uint32_t)__builtin_clzll(entered)) : 0u;
+    const uint32_t stream_end = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)last);
+    const uint32_t output_end = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)out_end, (int)last);  // (at most cap)
+    if (lane == 0) {
+      L.e_out[n] = output_end;
+      L.n_elems = entered ? n : 0u;
+      L.new_ip = entered ? stream_end : ip;  // (not entered cannot be: ip lies in the window)
+      L.out_end = entered ? output_end : op;
+      L.stopped = !entered || stops != 0;
+      L.e_lo = 0;
+    }
+    LW_STAMP(3)
   }
   __syncthreads();
-  LW_STAMP(1)
-  // ---- 2. the chain through the window
-  uint32_t entry = LW_NONE, first_elem = 0;
-  uint64_t first_out = 0;
-  {
-    uint32_t at = ip, elems = 0;
-    uint64_t made = op;
-    while (at < w0 + LW_WIN && at < in_end && made <= cap) {
-      const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
-      const uint32_t ex = lw_uni(L.u.p.exits[k * 33u + pl]), c = lw_uni(L.u.p.counts[k * 36u + pl]);
-      const uint32_t m = lw_uni(L.u.p.produce[k * 33u + pl]);
-      if (lane == k) {
-        entry = at;
-        first_elem = elems;
-        first_out = made;
-      }
-      elems += c;
-      made += m;
-      if (ex & LW_FAIL) break;
-      at = ex;
-    }
-  }
-  __syncthreads();  // the tables are done with: their room becomes the tile
-  LW_STAMP(2)
-  // ---- 3. this lane's elements
-  uint32_t mine = 0, end = 0;
-  uint64_t out_end = 0;
-  bool stop = false;
-  if (entry != LW_NONE) {
-    uint32_t q = entry, i = first_elem;
-    uint64_t o = first_out;
-    while (q < seg + 32u && q < in_end) {
-      const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
-      if (!s.ok || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
-        stop = true;
-        break;
-      }
-      if (s.lit_len) {
-        L.e_out[i] = (uint32_t)o;
-        L.e_src[i] = LW_LIT | s.lit_pos;
-        o += s.lit_len;
-        ++i;
-      }
-      if (s.mlen) {
-        L.e_out[i] = (uint32_t)o;
-        L.e_src[i] = s.offset;
-        o += s.mlen;
-        ++i;
-      }
-      q = s.next;
-    }
-    mine = i - first_elem;
-    end = q;
-    out_end = o;
-  }
-  // lanes behind one that stopped were entered for nothing
-  const uint64_t stops = __builtin_amdgcn_ballot_w64(stop);
-  if (stops && lane > (uint32_t)__builtin_ctzll(stops)) {
-    entry = LW_NONE;
-    mine = 0;
-  }
-  const uint64_t entered = __builtin_amdgcn_ballot_w64(entry != LW_NONE);
-  const uint32_t n_elems = lw_uni((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(mine), 63));
-  if (!entered) return true;  // (cannot be: ip lies in the window)
-  const uint32_t last = lw_uni(63u - (uint32_t)__builtin_clzll(entered));
-  const uint32_t new_ip = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)last);
-  const uint32_t o1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)out_end, (int)last);  // (at most cap)
-  const bool stopped = stops != 0;
-  if (lane == 0) L.e_out[n_elems] = o1;
-  __syncthreads();
-  LW_STAMP(3)
+  const uint32_t n_elems = L.n_elems, new_ip = L.new_ip, o1 = L.out_end;
+  const bool stopped = L.stopped;
   // ---- 4. the output, tile by tile
   const uint32_t o0 = op;
-  uint32_t e_lo = 0;  // elements below e_lo start at or in front of the tile
+  uint32_t* cell = L.u.x.cell;
+  uint32_t round = 0;  // (counts the rounds of all tiles: the flag of a round is flag[round % 3]; a flag is cleared a round before its use)
   for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
     const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
-    // element starts inside (tb, te): lane t holds the mask of bytes [64 t, 64 t + 64) of the tile
-    uint64_t starts = 0;
-    {
-      // (a lane per element; the masks are gathered through LDS words that the tile's pointers overwrite later)
-      uint32_t* words = L.u.x.cell;
-      words[lane] = 0;
-      words[lane + 64u] = 0;
-      __syncthreads();
-      // the element that holds byte tb: the last one that starts at or in front of it
+    if (wave == 0) {
+      // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane; elements below e_lo start at
+      // or in front of the tile
+      uint32_t e_lo = L.e_lo;
+      cell[lane] = 0;
+      cell[lane + 64u] = 0;
+      __builtin_amdgcn_wave_barrier();
       for (;;) {
         const uint32_t i = e_lo + lane;
         const bool in_front = i < n_elems && L.e_out[i] <= tb;
@@ -299,32 +323,34 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
         const uint32_t i = b + lane;
         const uint32_t eo = i < n_elems ? L.e_out[i] : 0xFFFFFFFFu;
         const bool inside = eo < te;
-        if (inside) atomicOr(&words[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
+        if (inside) atomicOr(&cell[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
         if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
       }
-      __syncthreads();
-      starts = (uint64_t)words[2u * lane] | ((uint64_t)words[2u * lane + 1u] << 32);
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t lo = cell[2u * lane], hi = cell[2u * lane + 1u];
+      const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
+      L.t_lo[lane] = lo;
+      L.t_hi[lane] = hi;
+      L.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
+      if (lane == 0) {
+        L.e_lo = e_lo;
+        L.flag[round % 3u] = 0;
+      }
     }
+    __syncthreads();
     LW_STAMP(4)
-    const uint32_t in_seg = (uint32_t)__builtin_popcountll(starts);
-    const uint32_t before = wave_scan_inclusive(in_seg) - in_seg;
     const uint32_t a = (uint32_t)((uintptr_t)(dst + tb) & 15u);
     const uint64_t upto = (2ull << lane) - 1ull;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles before this one are in memory
     // a word per byte of the tile: LW_HAS | the byte, or the tile position of the byte it repeats
-    uint32_t* cell = L.u.x.cell;
     const uint32_t n_steps = (te - tb + 63u) >> 6;
     bool open = false;
-    for (uint32_t t0 = 0; t0 < n_steps; t0 += LW_UNROLL) {
+    for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += LW_WAVES * LW_UNROLL) {
       uint32_t eo[LW_UNROLL], es[LW_UNROLL], word[LW_UNROLL];
 #pragma unroll
       for (uint32_t u = 0; u < LW_UNROLL; ++u) {
         const uint32_t t = t0 + u < n_steps ? t0 + u : n_steps - 1u;
-        const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)starts, (int)t);
-        const uint32_t s_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(starts >> 32), (int)t);
-        const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)before, (int)t);
-        uint32_t i = e_lo - 1u + bf + (uint32_t)__builtin_popcountll((((uint64_t)s_hi << 32) | s_lo) & upto);
+        const uint64_t st = ((uint64_t)L.t_hi[t] << 32) | L.t_lo[t];
+        uint32_t i = L.t_before[t] + (uint32_t)__builtin_popcountll(st & upto);
         i = i < n_elems ? i : n_elems - 1u;  // (bytes behind the output's end: any element, the result is not used)
         eo[u] = L.e_out[i];
         es[u] = L.e_src[i];
@@ -342,7 +368,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
             uint32_t from = o - es[u];
             if (rel >= es[u]) from = eo[u] - es[u] + rel % es[u];  // a match that repeats itself: the first period
             if (from < tb) {
-              word[u] = LW_HAS | (uint32_t)LW_FAR_LOAD(dst + from);  // (written by this wave: read where the stores went)
+              word[u] = LW_HAS | (uint32_t)LW_FAR_LOAD(dst + from);  // (written by this workgroup and waited for: read where the stores went)
             } else {
               word[u] = from - tb;
               open = true;
@@ -354,33 +380,41 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       for (uint32_t u = 0; u < LW_UNROLL; ++u)
         if (t0 + u < n_steps) cell[(t0 + u) * 64u + lane] = word[u];
     }
+    if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.flag[round % 3u] = 1;
     __syncthreads();
     LW_STAMP(5)
     // every byte follows its pointer until it arrives at a byte that has its value
-    while (__builtin_amdgcn_ballot_w64(open)) {
+    while (L.flag[round % 3u]) {
+      ++round;
+      if (tid == 0) L.flag[(round + 1u) % 3u] = 0;  // (the flag of the round after this one: last read two rounds ago)
+      const bool was_open = open;
       open = false;
-      for (uint32_t t0 = 0; t0 < n_steps; t0 += LW_UNROLL) {
-        uint32_t mine_[LW_UNROLL], other[LW_UNROLL];
+      if (__builtin_amdgcn_ballot_w64(was_open)) {
+        for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += LW_WAVES * LW_UNROLL) {
+          uint32_t mine_[LW_UNROLL], other[LW_UNROLL];
 #pragma unroll
-        for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
+          for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
 #pragma unroll
-        for (uint32_t u = 0; u < LW_UNROLL; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
+          for (uint32_t u = 0; u < LW_UNROLL; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
 #pragma unroll
-        for (uint32_t u = 0; u < LW_UNROLL; ++u) {
-          if (!(mine_[u] & LW_HAS)) {
-            cell[(t0 + u) * 64u + lane] = other[u];  // its value, or the byte that one repeats
-            open = open || !(other[u] & LW_HAS);
+          for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+            if (!(mine_[u] & LW_HAS)) {
+              cell[(t0 + u) * 64u + lane] = other[u];  // its value, or the byte that one repeats
+              open = open || !(other[u] & LW_HAS);
+            }
           }
         }
       }
+      if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.flag[round % 3u] = 1;
       __syncthreads();
     }
+    ++round;
     LW_STAMP(6)
     // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
     {
       PQD_GLOBAL uint8_t* gbase = dst + tb - a;  // 16-byte aligned
       const uint32_t stop_at = a + (te - tb);
-      for (uint32_t t = lane * 16u; t < stop_at; t += 1024u) {
+      for (uint32_t t = tid * 16u; t < stop_at; t += LW_WAVES * 1024u) {
         // the bytes of tile positions t - a .. t - a + 15
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -398,6 +432,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is in memory when the next one reads from it
     __syncthreads();
     LW_STAMP(7)
   }
@@ -410,25 +445,77 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
 __device__ __forceinline__ uint32_t lw_byte(const PQD_GLOBAL uint8_t* src, uint32_t pos) { return lw_uni(src[pos]); }
 
 __device__ __forceinline__ void lw_copy_literal(const PQD_GLOBAL uint8_t* from, PQD_GLOBAL uint8_t* to, uint32_t len, uint32_t lane) {
-  for (uint32_t i = lane; i < len; i += 64u) to[i] = from[i];
+  const uint32_t pieces = len >> 4;
+  uint32_t i = lane;
+  for (; i + 7u * 64u < pieces; i += 8u * 64u) {  // eight loads on their way before the first store
+    u32x4 v[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) __builtin_memcpy(&v[k], (const uint8_t*)(from + (i + k * 64u) * 16u), 16);
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) __builtin_memcpy((uint8_t*)(to + (i + k * 64u) * 16u), &v[k], 16);
+  }
+  for (; i < pieces; i += 64u) {
+    u32x4 v;
+    __builtin_memcpy(&v, (const uint8_t*)(from + i * 16u), 16);
+    __builtin_memcpy((uint8_t*)(to + i * 16u), &v, 16);
+  }
+  for (uint32_t j = (pieces << 4) + lane; j < len; j += 64u) to[j] = from[j];
 }
 
-// `len` bytes from `offset` back; lane l of a step takes the byte (l mod offset) - offset back of the step's start for
-// offsets below 64: the same byte of the repeating pattern, and one that is already written
+// `len` bytes from `offset` back (memory to memory; the bytes were stored by this workgroup and are waited for).
+// A match that reads its own output repeats the `offset` bytes in front of it: for offsets below 64 the lanes hold
+// that pattern and hand it round; longer ones are copied a period at a time.
 __device__ __forceinline__ void lw_copy_match(PQD_GLOBAL uint8_t* dst, uint32_t op, uint32_t offset, uint32_t len, uint32_t lane) {
-  uint32_t lm = lane;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (offset < 64u) {
+    uint32_t ph = lane;  // lane mod offset: six conditional subtractions
+    uint32_t step = 64u;  // 64 mod offset
 #pragma unroll
     for (int k = 5; k >= 0; --k) {
       const uint32_t t = offset << k;
-      lm = lm >= t ? lm - t : lm;
+      ph = ph >= t ? ph - t : ph;
+      step = step >= t ? step - t : step;
     }
+    step = step >= offset ? step - offset : step;
+    const uint32_t pattern = lane < offset ? (uint32_t)LW_FAR_LOAD(dst + (op - offset + lane)) : 0u;
+    for (uint32_t b = 0; b < len; b += 64u) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ph << 2), (int)pattern);
+      if (b + lane < len) dst[op + b + lane] = (uint8_t)v;
+      ph += step;
+      ph = ph >= offset ? ph - offset : ph;
+    }
+    return;
   }
-  // the bytes were stored by this wave: its stores are waited for, and the loads read where the stores went
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (uint32_t b = 0; b < len; b += 64u) {
-    if (len > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a match that reads its own output
-    if (b + lane < len) dst[op + b + lane] = __hip_atomic_load(dst + (op + b + lm - offset), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // pieces of at most `offset` bytes: a piece reads what lies in front of it
+  for (uint32_t done = 0; done < len;) {
+    const uint32_t piece = len - done < offset ? len - done : offset;
+    if (done) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t i = lane; i < piece; i += 64u) dst[op + done + i] = LW_FAR_LOAD(dst + (op + done + i - offset));
+    done += piece;
+  }
+}
+
+// LZ4's length bytes (each adds its value; the first one below 255 is the last), 64 at a time.  false: the stream ends
+// inside them (ip then lies at its end, as a byte-by-byte reader leaves it).
+__device__ __forceinline__ bool lw_length_bytes(const PQD_GLOBAL uint8_t* src, uint32_t& ip, uint32_t in_end, uint64_t& sum, uint32_t lane) {
+  for (;;) {
+    const bool inside = ip + lane < in_end;
+    const uint32_t b = inside ? (uint32_t)src[ip + lane] : 0u;
+    const uint64_t ends = __builtin_amdgcn_ballot_w64(!inside || b != 255u);
+    if (!ends) {
+      sum += 64u * 255u;
+      ip += 64u;
+      continue;
+    }
+    const uint32_t at = lw_uni((uint32_t)__builtin_ctzll(ends));
+    sum += 255u * at;
+    if (ip + at >= in_end) {
+      ip = in_end;
+      return false;
+    }
+    sum += (uint32_t)__builtin_amdgcn_readlane((int)b, (int)at);
+    ip += at + 1u;
+    return true;
   }
 }
 
@@ -471,15 +558,7 @@ __device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL
   const uint32_t token = lw_byte(src, ip);
   ++ip;
   uint64_t lit = token >> 4;
-  if (lit == 15u) {
-    uint32_t b;
-    do {
-      if (ip >= in_end) return false;
-      b = lw_byte(src, ip);
-      ++ip;
-      lit += b;
-    } while (b == 255u);
-  }
+  if (lit == 15u && !lw_length_bytes(src, ip, in_end, lit, lane)) return false;
   if (lit > in_end - ip || lit > cap - op) return false;
   lw_copy_literal(src + ip, dst + op, (uint32_t)lit, lane);
   op += (uint32_t)lit;
@@ -489,15 +568,7 @@ __device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL
   const uint32_t offset = lw_byte(src, ip) | (lw_byte(src, ip + 1u) << 8);
   ip += 2u;
   uint64_t mlen = token & 15u;
-  if (mlen == 15u) {
-    uint32_t b;
-    do {
-      if (ip >= in_end) return false;
-      b = lw_byte(src, ip);
-      ++ip;
-      mlen += b;
-    } while (b == 255u);
-  }
+  if (mlen == 15u && !lw_length_bytes(src, ip, in_end, mlen, lane)) return false;
   mlen += 4u;
   if (offset == 0u || offset > op || mlen > cap - op) return false;
   lw_copy_match(dst, op, offset, (uint32_t)mlen, lane);
@@ -506,16 +577,16 @@ __device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL
 }
 
 template <int CODEC>
-__global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
-                                                 pqd_page_result* __restrict__ results, uint32_t n_pages) {
+__global__ __launch_bounds__(LW_WAVES * 64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
+                                                            pqd_page_result* __restrict__ results, uint32_t n_pages) {
   __shared__ LwLds L;
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
   if (d.codec != (uint32_t)CODEC) return;  // another kernel's page
-  const uint32_t lane = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
   if (d.src_len > 0x7fffffffu) {
-    if (lane == 0) {
+    if (tid == 0) {
       pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
       results[page] = r;
     }
@@ -552,9 +623,24 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
 #endif
   if (status == PQD_OK) {
     while (ip < in_end) {
-      if (!lw_window<CODEC>(L, src, dst, ip, op, in_end, cap, lane LW_PROF_PASS)) continue;
+      if (!lw_window<CODEC>(L, src, dst, ip, op, in_end, cap, tid LW_PROF_PASS)) continue;
       if (ip >= in_end) break;
-      if (!lw_one<CODEC>(src, dst, ip, op, in_end, cap, lane)) {
+      // one sequence by the first wave; the others learn where it ended
+      if (tid < 64u) {
+        const bool fine = lw_one<CODEC>(src, dst, ip, op, in_end, cap, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+          L.new_ip = ip;
+          L.out_end = op;
+          L.stopped = !fine;
+        }
+      }
+      __syncthreads();
+      ip = L.new_ip;
+      op = L.out_end;
+      const bool failed = L.stopped;
+      __syncthreads();
+      if (failed) {
         status = PQD_DECODE;
         break;
       }
@@ -562,14 +648,14 @@ __global__ __launch_bounds__(64) void k_lz_pages(const pqd_decompress_desc* __re
     // the stream produces what its preamble announced (Snappy), and the page what its header announced
     if (status == PQD_OK && ((CODEC == PQD_CODEC_SNAPPY && op != ulen) || op != cap)) status = PQD_DECODE;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     pqd_page_result r = {status, op, ip, 0u};
     results[page] = r;
   }
 #ifdef LW_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0 && cap >= 64u)
-    for (int k = 0; k < 8; ++k) reinterpret_cast<PQD_GLOBAL uint64_t*>(dst)[k] = prof[k];
+  if (tid == 0 && cap >= 64u)
+    for (int k = 0; k < 8; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
 #endif
 }
 
@@ -605,9 +691,9 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
 
 static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
   if (codec == PQD_CODEC_SNAPPY)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY>), dim3(n_pages), dim3(LW_WAVES * 64), 0, stream, descs, results, n_pages);
   else if (codec == PQD_CODEC_LZ4_RAW)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW>), dim3(n_pages), dim3(LW_WAVES * 64), 0, stream, descs, results, n_pages);
 }
 
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,

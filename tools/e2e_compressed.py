@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--values", type=int, default=16_000_000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--codecs", default="SNAPPY,LZ4_RAW,ZSTD,GZIP")
+    ap.add_argument("--host-threads", type=int, default=1, help="threads that decompress pages in the host flow")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     pq.init(0)
@@ -68,11 +69,14 @@ def main():
         "dictionary": (rng.integers(0, 1 << 62, 65536)[(np.arange(n) // 50 + rng.integers(0, 16, n)) & 0xFFFF], True),
         "plain_timestamps": (1_600_000_000_000 + np.cumsum(rng.integers(0, 2000, n)), False),
     }
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(args.host_threads) if args.host_threads > 1 else None
     stream = C.c_void_p()
     pq.check(pq.lib.pqd_stream_create(C.byref(stream)))
     s = stream.value
     h_out = pinned(n * 8)
     d_val = torch.zeros(n + 64, dtype=torch.int64, device=dev)
+    print(f"host flow decompresses with {args.host_threads} thread(s)")
     print(f"{n} INT64 values per chunk ({n * 8 / 1e6:.0f} MB decoded), 1 MiB pages, {args.steps} steps; rates are decoded bytes per second of wall clock")
     for cname, (values, dictionary) in columns.items():
         for codec in ["UNCOMPRESSED"] + args.codecs.split(","):
@@ -138,16 +142,25 @@ def main():
             def host_flow():
                 codec_obj = pa.Codec(pa_name) if pa_name else None
                 bodies = as_numpy(h_bodies, bodies_cap)
-                unc, at = [], 0
+                unc, at, jobs = [], 0, []
                 for p in pages:
-                    src = chunk[p.body_offset:p.body_offset + p.compressed_size]
-                    if codec_obj is not None:
-                        src = codec_obj.decompress(src, decompressed_size=p.uncompressed_size)
-                    bodies[at:at + p.uncompressed_size] = np.frombuffer(src, np.uint8)
                     q = pq.ChunkPage.from_buffer_copy(bytes(p))
                     q.body_offset, q.compressed_size, q.is_compressed = at, p.uncompressed_size, 0
                     unc.append(q)
+                    jobs.append((p, at))
                     at += (p.uncompressed_size + 15) & ~15
+
+                def one(job):
+                    p, to = job
+                    src = chunk[p.body_offset:p.body_offset + p.compressed_size]
+                    if codec_obj is not None:
+                        src = codec_obj.decompress(src, decompressed_size=p.uncompressed_size)
+                    bodies[to:to + p.uncompressed_size] = np.frombuffer(src, np.uint8)
+                if pool is None:
+                    for job in jobs:
+                        one(job)
+                else:
+                    list(pool.map(one, jobs, chunksize=8))
                 pq.check(pq.lib.pqd_memcpy_h2d(d_bodies.data_ptr(), h_bodies, at, s))
                 decode(unc, d_bodies.data_ptr())
 

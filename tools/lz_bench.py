@@ -20,7 +20,7 @@ NUM = {"snappy": 1, "gzip": 2, "zstd": 6, "lz4_raw": 7}
 def main():
     n_p = int(os.environ.get("LZB_PAGES", "256"))
     distinct = int(os.environ.get("LZB_DISTINCT", "16"))
-    size = 1 << 20
+    size = int(os.environ.get("LZB_SIZE", str(1 << 20)))
     dev = torch.device("cuda:0")
     pq.init(0)
     stream = torch.cuda.current_stream().cuda_stream
@@ -31,6 +31,7 @@ def main():
         "doubles": lambda r: np.round(r.normal(size=size // 8), 2).astype("<f8").tobytes(),
         "random": lambda r: r.integers(0, 256, size, dtype=np.uint8).tobytes(),
         "zeros": lambda r: bytes(size),
+        "ids": lambda r: ((np.arange(size // 2) // 50 + r.integers(0, 16, size // 2)) & 0xFFFF).astype("<u2").tobytes(),
     }
     for kind in os.environ.get("LZB_KINDS", "text,ints,doubles").split(","):
         raws = [makers[kind](np.random.default_rng(100 + i)) for i in range(distinct)]
@@ -56,6 +57,8 @@ def main():
                 c = out[0][:64].cpu().numpy().view(np.uint64)
                 print("   cycles/1000 of page 0: stage %d, places %d, chain %d, elements %d, masks %d, classify %d, resolve %d, store %d"
                       % tuple(int(x) // 1000 for x in c))
+                if os.environ.get("LZB_PROF") == "raw":
+                    print("   raw counters:", [int(x) for x in c])
                 ok = True
             ts = []
             for _ in range(3):
