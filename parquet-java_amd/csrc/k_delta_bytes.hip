@@ -6,14 +6,16 @@
 // bytes, which lie back to back behind the length block: one 256-thread workgroup per page.
 // DeltaByteArrayReader.readBytes (.../deltastrings/DeltaByteArrayReader.java:63-85) builds value i from
 // the first prefix[i] bytes of value i-1 and suffix i, a chain through the whole page.  One wave per
-// page takes 64 values at a time: the suffixes of the batch are staged in LDS, then for every byte
-// column j below the longest prefix one ballot tells each lane the last value at or before it whose
-// own bytes start at or before column j (its suffix holds byte j of every value up to the next such
-// value); columns no value of the batch owns come from the value before the batch, whose leading bytes
-// are kept in LDS.  The assembled values leave through an LDS tile in aligned 16-byte stores.
-// Values or prefixes too long for the tiles are copied one value at a time through global memory.
+// page takes 64 values at a time: the suffixes of the batch are staged in LDS; then the lanes are byte
+// columns (lane l holds byte l and byte l + 64 of the current value in registers) and the values go by
+// one after the other: a column inside the value's prefix keeps its byte, a column inside its suffix
+// takes the suffix's byte, and the columns write the value into an LDS tile.  Carrying a prefix over
+// costs nothing that way, and no step waits for the one before it (the suffix bytes of four values
+// are fetched before they are used).  The tile leaves in aligned 16-byte stores.
+// Values of more than 128 bytes, or too long for the tiles, are copied one at a time through global memory.
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
+#include "pqd_lz_common.hpp"
 
 namespace pqd {
 
@@ -21,6 +23,11 @@ constexpr int DL_THREADS = 256;
 constexpr int DL_PER_LANE = 16;
 constexpr uint32_t DL_TILE = DL_THREADS * DL_PER_LANE;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+#ifdef DB_PROF
+#define DB_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); prof[k] += now_ - prof_t; prof_t = now_; }
+#else
+#define DB_STAMP(k)
+#endif
 
 struct LengthBlocks {
   int32_t status;   // of the length block(s): not PQD_OK fails the page before its first value
@@ -149,9 +156,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_delta_length_bytes(const pqd_del
 
 // ---- DELTA_BYTE_ARRAY ---------------------------------------------------------------------------------
 
-constexpr uint32_t DB_IN = 8192;    // suffix bytes of a batch staged in LDS
+constexpr uint32_t DB_IN = LZ_CHUNK;  // suffix bytes of a batch at most: they lie in the two chunks of the suffix stream that LDS holds
 constexpr uint32_t DB_OUT = 8192;   // assembled bytes of a batch
-constexpr uint32_t DB_KEEP = 1024;  // leading bytes kept of the value before the batch
+constexpr uint32_t DB_COLUMNS = 128; // byte columns held in the lanes' registers: longer values go one at a time
 
 __device__ __forceinline__ uint32_t shuffle_u32(uint32_t v, uint32_t from_lane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
@@ -164,9 +171,8 @@ __device__ __forceinline__ uint8_t load_written_byte(const PQD_GLOBAL uint8_t* p
 
 __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_desc* __restrict__ descs,
                                                          pqd_page_result* __restrict__ results, uint32_t n_pages) {
-  __shared__ __attribute__((aligned(16))) uint8_t in_tile[DB_IN + 16];
-  __shared__ __attribute__((aligned(16))) uint8_t out_tile[DB_OUT + 32];
-  __shared__ uint8_t keep[DB_KEEP];
+  __shared__ __attribute__((aligned(16))) uint8_t in_stage[LZ_STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t out_tile[DB_OUT + 16 + DB_COLUMNS + 16];  // (lanes write up to 128 bytes behind a value's start)
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_delta_bytes_desc b = descs[page];
@@ -189,23 +195,48 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
   const uint64_t savail = b.data_len - lb.header;
   const uint64_t cap = b.bytes_capacity > 0x7fffffffu ? 0x7fffffffull : (uint64_t)b.bytes_capacity;
 
+  // the suffix bytes are streamed through LDS, the chunk behind the ones in use already on its way
+  InStage in;
+  in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)sdata & ~(uintptr_t)15);
+  const uint32_t skew = (uint32_t)((uintptr_t)sdata & 15u);
+  in.end = skew + (uint32_t)savail;
+  in.lane = lane;
+  in.lds = in_stage;
+  in.cur = 0;
+  in.start(0);
   // the value before the page
   uint32_t last_len = 0;
-  const PQD_GLOBAL uint8_t* last_ptr = nullptr;  // its bytes in global memory (for prefixes longer than `keep`)
+  const PQD_GLOBAL uint8_t* last_ptr = nullptr;  // its bytes in global memory
+  uint32_t c0 = 0, c1 = 0;                        // its bytes lane and lane + 64
   if (b.prev_bytes && b.prev_offsets && b.prev_count) {
     const int32_t p0 = b.prev_offsets[b.prev_count - 1], p1 = b.prev_offsets[b.prev_count];
     last_len = p1 > p0 ? (uint32_t)(p1 - p0) : 0u;
     last_ptr = (const PQD_GLOBAL uint8_t*)b.prev_bytes + p0;
-    for (uint32_t t = lane; t < last_len && t < DB_KEEP; t += 64) keep[t] = last_ptr[t];
+    if (lane < last_len) c0 = last_ptr[lane];
+    if (lane + 64u < last_len) c1 = last_ptr[lane + 64u];
   }
 
   uint32_t i0 = 0;
   uint64_t run_out = 0, run_in = 0;
   int32_t status = PQD_OK;
+  // The lengths of the two batches to come are fetched ahead.  (A wait for a load also waits for every store issued
+  // before it: lengths fetched one batch ahead would wait for the batch's own output to reach memory, every batch.)
+  int32_t P1 = lane < n ? prefix[lane] : 0, S1 = lane < n ? suffix[lane] : 0;
+  int32_t P2 = lane + 64u < n ? prefix[lane + 64u] : 0, S2 = lane + 64u < n ? suffix[lane + 64u] : 0;
+  uint32_t at1 = 0, at2 = 64;  // the first value of those batches, if the batches in front of them take 64 values each
+#ifdef DB_PROF
+  uint64_t prof[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_readcyclecounter();
+#endif
   while (i0 < n) {
+    DB_STAMP(5)
     const uint32_t idx = i0 + lane;
     const bool valid = idx < n;
-    const int32_t P = valid ? prefix[idx] : 0, S = valid ? suffix[idx] : 0;
+    if (at1 != i0) {  // a batch was cut short
+      P1 = valid ? prefix[idx] : 0;
+      S1 = valid ? suffix[idx] : 0;
+    }
+    const int32_t P = P1, S = S1;
     const bool negative = P < 0 || S < 0;
     const uint32_t p = negative ? 0u : (uint32_t)P, s = negative ? 0u : (uint32_t)S;
     const uint64_t len = (uint64_t)p + s;
@@ -222,25 +253,41 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
       break;
     }
     // how many of them fit the tiles
-    const bool fits = oo_inc <= DB_OUT && so_inc <= DB_IN && p <= DB_KEEP;
+    const bool fits = oo_inc <= DB_OUT && so_inc <= DB_IN && len <= DB_COLUMNS;
     const uint64_t unfit_mask = __ballot(!fits);
     uint32_t m = unfit_mask ? (uint32_t)__builtin_ctzll(unfit_mask) : 64u;
     m = m < deliverable ? m : deliverable;
     PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)b.bytes + run_out;
+    DB_STAMP(0)
+    {
+      const uint32_t next = i0 + (m ? m : 1u);
+      if (at2 == next) {
+        P1 = P2;
+        S1 = S2;
+        at1 = at2;
+      } else {
+        P1 = next + lane < n ? prefix[next + lane] : 0;
+        S1 = next + lane < n ? suffix[next + lane] : 0;
+        at1 = next;
+      }
+      at2 = next + 64u;
+      P2 = at2 + lane < n ? prefix[at2 + lane] : 0;
+      S2 = at2 + lane < n ? suffix[at2 + lane] : 0;
+    }
     if (m == 0) {
       // one value through global memory: its prefix from where the value before it was written
       const uint32_t p0 = __builtin_amdgcn_readfirstlane(p), s0 = __builtin_amdgcn_readfirstlane(s);
       __threadfence();
       for (uint32_t t = lane; t < p0; t += 64) dst[t] = load_written_byte(last_ptr + t);
       const PQD_GLOBAL uint8_t* src = sdata + run_in;
-      for (uint32_t t = lane; t < s0; t += 64) {
-        const uint8_t v = src[t];
-        dst[p0 + t] = v;
-        if (p0 + t < DB_KEEP) keep[p0 + t] = v;
-      }
+      for (uint32_t t = lane; t < s0; t += 64) dst[p0 + t] = src[t];
       if (lane == 0) offsets[i0] = (int32_t)run_out;
       last_ptr = dst;
       last_len = p0 + s0;
+      // the columns' registers: the value's first 128 bytes, read back
+      __threadfence();
+      if (lane < last_len) c0 = load_written_byte(dst + lane);
+      if (lane + 64u < last_len) c1 = load_written_byte(dst + lane + 64u);
       run_out += (uint64_t)p0 + s0;
       run_in += s0;
       i0 += 1;
@@ -249,73 +296,52 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     const uint32_t in_bytes = shuffle_u32((uint32_t)so_inc, m - 1);
     const uint32_t out_bytes = shuffle_u32((uint32_t)oo_inc, m - 1);
     const bool mine = lane < m;
-    // suffix bytes of the batch -> LDS
-    {
-      const PQD_GLOBAL uint8_t* src = sdata + run_in;
-      const uint64_t left = savail - run_in;  // bytes that exist behind src
-      for (uint32_t t = lane * 16u; t < in_bytes; t += 1024u) {
-        if ((uint64_t)t + 16u <= left) {
-          u32x4 v;
-          __builtin_memcpy(&v, src + t, 16);
-          *reinterpret_cast<u32x4*>(in_tile + t) = v;
-        } else {
-          for (uint32_t k = 0; t + k < in_bytes; ++k) in_tile[t + k] = src[t + k];
-        }
-      }
-    }
+    // the batch's suffix bytes: stream positions first .. first + in_bytes, at most DB_IN of them
+    const uint32_t first = skew + (uint32_t)run_in;
+    DB_STAMP(1)
+    in.reach(first);
+    DB_STAMP(2)
     // the tile is laid out like the destination: byte x of the batch at out_tile[a + x]
     const uint32_t a = (uint32_t)((uintptr_t)dst & 15u);
     const uint32_t o = a + (uint32_t)oo;  // this lane's value in the tile
     __syncthreads();  // (one wave: only an order for the LDS accesses)
-    // prefix columns
-    uint32_t longest = mine ? p : 0u;
+    // the values in order, a lane per byte column.  Every lane reads and writes for every value: a read outside the
+    // value's suffix is not used, a write behind the value's end lands where a later value (or nobody) writes.
+    // (prefix and suffix lengths are below 2^16 here, tile positions below 2^14: two values per register to hand round)
+    const uint32_t ps = p | (s << 16), so_o = ((first + (uint32_t)so - p) & (LZ_STAGE - 1u)) | (o << 16);
+    for (uint32_t k0 = 0; k0 < m; k0 += 4u) {
+      uint32_t pk[4], sk[4], to[4], base[4], r0[4], r1[4];
+      bool wide = false;
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) {
-      const uint32_t other = shuffle_u32(longest, lane ^ (uint32_t)sh);
-      longest = other > longest ? other : longest;
-    }
-    longest = __builtin_amdgcn_readfirstlane(longest);
-    const uint32_t own_base = (uint32_t)so - p;  // in_tile index of this value's byte j is own_base + j (j >= p)
-    const uint64_t below = (2ull << lane) - 1ull;
-    for (uint32_t j = 0; j < longest; ++j) {
-      const uint64_t owners = __ballot(mine && p <= j) & below;
-      const uint32_t owner = owners ? 63u - (uint32_t)__builtin_clzll(owners) : 0u;
-      const uint32_t base = shuffle_u32(own_base, owner);
-      if (mine && j < p) {
-        const uint8_t v = owners ? in_tile[base + j] : keep[j];
-        out_tile[o + j] = v;
-        if (lane == m - 1) keep[j] = v;
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t k = k0 + u < m ? k0 + u : m - 1u;  // (behind the batch: its last value once more, which changes nothing)
+        const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)k), b_ = (uint32_t)__builtin_amdgcn_readlane((int)so_o, (int)k);
+        pk[u] = a_ & 0xFFFFu;
+        sk[u] = a_ >> 16;
+        base[u] = b_ & 0xFFFFu;  // where the byte of column 0 would lie in the stage, if the suffix began there
+        to[u] = b_ >> 16;
+        wide = wide || pk[u] + sk[u] > 64u;
+        r0[u] = in_stage[(base[u] + lane) & (LZ_STAGE - 1u)];
       }
-    }
-    // suffixes
-    {
-      uint32_t longest_s = mine ? s : 0u;
+      if (wide) {
 #pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) {
-        const uint32_t other = shuffle_u32(longest_s, lane ^ (uint32_t)sh);
-        longest_s = other > longest_s ? other : longest_s;
-      }
-      longest_s = __builtin_amdgcn_readfirstlane(longest_s);
-      if (longest_s <= 64u) {
-        for (uint32_t t = 0; t < longest_s; ++t) {
-          if (mine && t < s) {
-            const uint8_t v = in_tile[(uint32_t)so + t];
-            out_tile[o + p + t] = v;
-            if (lane == m - 1 && p + t < DB_KEEP) keep[p + t] = v;
-          }
+        for (uint32_t u = 0; u < 4u; ++u) r1[u] = in_stage[(base[u] + lane + 64u) & (LZ_STAGE - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          c0 = lane - pk[u] < sk[u] ? r0[u] : c0;
+          c1 = lane + 64u - pk[u] < sk[u] ? r1[u] : c1;
+          out_tile[to[u] + lane] = (uint8_t)c0;
+          out_tile[to[u] + lane + 64u] = (uint8_t)c1;
         }
       } else {
-        for (uint32_t k = 0; k < m; ++k) {  // one value after the other, the lanes side by side
-          const uint32_t ks = shuffle_u32(s, k), kso = shuffle_u32((uint32_t)so, k), ko = shuffle_u32(o + p, k);
-          const uint32_t kp = shuffle_u32(p, k);
-          for (uint32_t t = lane; t < ks; t += 64) {
-            const uint8_t v = in_tile[kso + t];
-            out_tile[ko + t] = v;
-            if (k == m - 1 && kp + t < DB_KEEP) keep[kp + t] = v;
-          }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          c0 = lane - pk[u] < sk[u] ? r0[u] : c0;
+          out_tile[to[u] + lane] = (uint8_t)c0;
         }
       }
     }
+    DB_STAMP(3)
     if (mine) offsets[idx] = (int32_t)(run_out + oo);
     __syncthreads();
     // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
@@ -337,7 +363,13 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     run_in += in_bytes;
     i0 += m;
     __syncthreads();
+    DB_STAMP(4)
   }
+#ifdef DB_PROF
+  if (page == 0 && lane == 0)
+    printf("cycles/1000: scans %llu, next lengths %llu, reach %llu, columns %llu, store %llu, loop %llu\n", prof[0] / 1000, prof[1] / 1000,
+           prof[2] / 1000, prof[3] / 1000, prof[4] / 1000, prof[5] / 1000);
+#endif
   if (status == PQD_OK && i0 < b.num_values) status = PQD_DECODE;  // "no more value to read" from a length block
   if (lane == 0) {
     offsets[i0] = (int32_t)run_out;
