@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
                                                            const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                            const uint32_t* __restrict__ cursor, uint32_t* __restrict__ zero,
                                                            uint32_t zero_words) {
-  constexpr int LDS_PIECES = HAS_DICT && (sizeof(WholePageLds) + 15) / 16 > WINDOW_PIECES ? (int)((sizeof(WholePageLds) + 15) / 16) : WINDOW_PIECES;
+  constexpr int LDS_PIECES = (sizeof(WholePageLds) + 15) / 16 > WINDOW_PIECES ? (int)((sizeof(WholePageLds) + 15) / 16) : WINDOW_PIECES;
   __shared__ u32x4 win4[LDS_PIECES];  // the page decoder's window; the other parts of this kernel use it when no page is being decoded
   // the counter block of the NEXT call on this stream (nothing in this call reads or writes it)
   for (uint32_t i = blockIdx.x * RLE_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * RLE_THREADS) zero[i] = 0u;
@@ -314,6 +314,11 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
           if (dict_whole_page<ELEM>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) continue;
           __syncthreads();
         }
+      } else {
+        if (f == PLAN_F_WHOLE) {  // run-heavy pages of dictionary ids read as ints
+          if (dict_whole_page<4, true>(d, results + page, *reinterpret_cast<WholePageLds*>(win4))) continue;
+          __syncthreads();
+        }
       }
       rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
     }
@@ -336,7 +341,7 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
   const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
   // with a plan: a grid that strides over the left-over pages (few) and, for dictionary pages, over the direct chunks
-  const uint32_t cap = has_dict && sp ? 1024u : 512u;
+  const uint32_t cap = has_dict && sp ? 1024u : 1280u;  // (five workgroups of this kernel fit a CU)
   const dim3 grid(pl && n_pages > cap ? cap : n_pages), block(RLE_THREADS);
   if (!has_dict)
     hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor, zero, zero_words);

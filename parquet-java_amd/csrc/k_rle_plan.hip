@@ -650,6 +650,15 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     }
     return;
   }
+  // The same for run-heavy pages of dictionary ids that are read as ints (a width byte in front, no dictionary).
+  if (!want_dict && (d.flags & PQD_F_WIDTH_PREFIX) && whole_page_candidate(end - pos, n_values, w, 1u, whole_max)) {
+    if (tid == 0) {
+      plans[page].flags = PLAN_F_WHOLE;
+      cursor[PLAN_CTR_FALLBACK] = 1u;  // (the left-over launch of plain pages looks at this flag only)
+      if (page < pool_chunks) write_empty_chunk(pool, page);
+    }
+    return;
+  }
   // Not for the planned kernels: pages of more than 2^30 values (segment starts hold 30 bits);
   // dictionary pages with ids wider than 16 bits, or whose dictionary is misaligned or too large
   // for streaming it through LDS to be cheaper than a direct gather.

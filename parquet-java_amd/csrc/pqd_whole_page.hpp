@@ -101,7 +101,7 @@ static_assert(WP_VAL_RUNS * 12u <= sizeof(uint16_t) * (WP_MAX_BYTES + 64) && (WP
 // values; v_base: the page's values before the window); x[k].y is
 // meaningless for 4-byte dictionaries.  FAST: the entries of RLE runs were looked up once per run and are read from
 // LDS; only values of bit-packed groups are fetched from the dictionary.
-template <int ELEM, bool FAST>
+template <int ELEM, bool FAST, bool IDENT>
 __device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d, uint32_t v0, uint32_t n_values, uint32_t v_base,
                                         uint32_t w, uint32_t mask, u32x2 x[4]) {
   const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
@@ -124,14 +124,18 @@ __device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d,
       const uint32_t bit = (e & 0x7FFFFFFFu) + vw;
       const uint32_t i0 = (bit >> 5) & (WP_MAX_BYTES / 4 - 1u);  // (an RLE entry gives a meaningless but harmless index)
       uint32_t id = (e >> 31) ? funnel_shr(pgw[i0], pgw[i0 + 1], bit & 31u) & mask : e;
-      if (id >= d.dict_len) {  // ColumnReaderBase.java:582-616: the first such value ends what the page delivers
-        if (v0 + k < n_values) atomicMin(&L.oob_at, v_base + v0 + k);
-        id = 0u;
+      if (IDENT) {
+        x[k].x = id;  // readValueDictionaryId: the id is the value
+      } else {
+        if (id >= d.dict_len) {  // ColumnReaderBase.java:582-616: the first such value ends what the page delivers
+          if (v0 + k < n_values) atomicMin(&L.oob_at, v_base + v0 + k);
+          id = 0u;
+        }
+        if (ELEM == 4)
+          x[k].x = ((const PQD_GLOBAL uint32_t*)d.dict)[id];
+        else
+          x[k] = ((const PQD_GLOBAL u32x2_a4*)d.dict)[id];
       }
-      if (ELEM == 4)
-        x[k].x = ((const PQD_GLOBAL uint32_t*)d.dict)[id];
-      else
-        x[k] = ((const PQD_GLOBAL u32x2_a4*)d.dict)[id];
     }
     vw += w;
   }
@@ -139,7 +143,7 @@ __device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d,
 
 // Step 5 of dict_whole_page: per step two units of four values per thread, their lookups requested together (n_values:
 // the window's values; v_base: the page's values before it).
-template <int ELEM, bool FAST>
+template <int ELEM, bool FAST, bool IDENT>
 __device__ __forceinline__ void wp_values(WholePageLds& L, const pqd_page_desc& d, uint32_t n_values, uint32_t v_base, uint32_t w) {
   const uint32_t mask = (1u << w) - 1u;
   constexpr uint32_t STEP = WP_THREADS * 4u;
@@ -148,7 +152,7 @@ __device__ __forceinline__ void wp_values(WholePageLds& L, const pqd_page_desc& 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const uint32_t vv = v0 + (uint32_t)u * STEP;
-      if (vv < n_values) wp_unit<ELEM, FAST>(L, d, vv, n_values, v_base, w, mask, x[u]);
+      if (vv < n_values) wp_unit<ELEM, FAST, IDENT>(L, d, vv, n_values, v_base, w, mask, x[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -186,11 +190,13 @@ __device__ __forceinline__ void wp_values(WholePageLds& L, const pqd_page_desc& 
 // One dictionary page (d.data = [width][stream]) by the calling workgroup of WP_THREADS threads; L: its LDS, free for
 // this call.  The stream is taken a window of WP_MAX_BYTES at a time; a window ends in front of the first run that does
 // not fit into it.  false (for all threads): not decoded (what was written is written again by the caller's decoder).
-template <int ELEM>
+// IDENT: a page of dictionary ids read as ints (PQD_ENC_RLE with PQD_F_WIDTH_PREFIX, DictionaryValuesReader.readValueDictionaryId):
+// the same stream, the id itself is the value and no dictionary is looked at.
+template <int ELEM, bool IDENT = false>
 __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result, WholePageLds& L) {
   const uint32_t tid = threadIdx.x;
   const uint32_t n_page_values = d.num_values;
-  if (d.data_len < 2u || d.dict == nullptr) return false;
+  if (d.data_len < 2u || (!IDENT && d.dict == nullptr)) return false;
   const uint32_t n_stream = d.data_len - 1u;
   if (n_stream > WP_MAX_STREAM || n_page_values == 0u || n_page_values > WP_MAX_VALUES) return false;
   // the width byte is requested here and looked at behind the first staging step: one trip to memory for both
@@ -245,7 +251,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       L.n_eff = N;
     }
     __syncthreads();
-    if (!whole_page_candidate(n_stream, n_page_values, w, d.dict_len, WP_MAX_STREAM)) return false;
+    if (!whole_page_candidate(n_stream, n_page_values, w, IDENT ? 1u : d.dict_len, WP_MAX_STREAM)) return false;
     const uint32_t vb = (w + 7u) >> 3;
     const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
 
@@ -388,7 +394,9 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       for (uint32_t r = tid; r < n_runs; r += WP_THREADS) {
         const uint32_t e = runs_c[r];
         if (e >> 31) continue;
-        if (e >= d.dict_len) {
+        if (IDENT) {
+          vals[r] = e;
+        } else if (e >= d.dict_len) {
           L.rle_oob = 1u;
         } else if (ELEM == 4) {
           vals[r] = ((const PQD_GLOBAL uint32_t*)d.dict)[e];
@@ -401,9 +409,9 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     }
     WP_STAMP();
     if (fast)
-      wp_values<ELEM, true>(L, d, nv, v_base, w);
+      wp_values<ELEM, true, IDENT>(L, d, nv, v_base, w);
     else
-      wp_values<ELEM, false>(L, d, nv, v_base, w);
+      wp_values<ELEM, false, IDENT>(L, d, nv, v_base, w);
     __syncthreads();  // the window's LDS is done with
     WP_STAMP();
     v_base += nv;
