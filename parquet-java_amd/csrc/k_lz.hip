@@ -49,6 +49,7 @@ namespace pqd {
 constexpr uint32_t LW_WIN = 2048;    // stream bytes per window
 constexpr uint32_t LW_SLACK = 96;    // staged behind it: the headers of sequences that start in the window's last places
 constexpr uint32_t LW_LENGTH_BYTES = 4;  // LZ4 length bytes read per length in the windows
+constexpr uint32_t LW_HUGE = 1u << 18;  // elements from this length on are left to the wave-uniform code
 constexpr uint32_t LW_TILE = 4096;   // output bytes per tile
 constexpr uint32_t LW_ELEMS = 1408;  // elements per window at most (Snappy: 2 bytes each; LZ4: 2 per 3 bytes)
 constexpr uint32_t LW_FAIL = 0x80000000u, LW_NONE = 0xFFFFFFFFu, LW_LIT = 0x80000000u;
@@ -61,16 +62,16 @@ constexpr uint32_t LW_HAS = 0x80000000u;  // a tile cell that holds its byte
 #endif
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-// window byte q in LDS: four bytes of padding behind every 32-byte segment (the lanes' segments start in different banks)
-__device__ __forceinline__ uint32_t lw_at(uint32_t q) { return q + ((q >> 5) << 2); }
+// window byte q in LDS (no padding between the lanes' segments: the instructions of an address with padding cost more
+// than the bank conflicts of one without)
+__device__ __forceinline__ uint32_t lw_at(uint32_t q) { return q; }
 
 struct LwLds {
-  uint8_t win[LW_WIN + LW_SLACK + 4 * ((LW_WIN + LW_SLACK) / 32 + 2)];
+  __attribute__((aligned(16))) uint8_t win[LW_WIN + LW_SLACK + 32];
   union {
-    struct {  // parse
-      uint32_t exits[64 * 33];   // where the chain from a place leaves the segment (LW_FAIL: it stops inside)
-      uint32_t produce[64 * 33]; // output bytes of the sequences on the way
-      uint8_t counts[64 * 36];   // elements on the way
+    struct {  // parse: per place .x = where the chain from it leaves the segment (LW_FAIL: it stops inside),
+              // .y = elements on the way << 24 | output bytes of the sequences on the way
+      u32x2 place[64 * 33];
     } p;
     struct {  // execute
       uint32_t cell[LW_TILE];
@@ -107,26 +108,26 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
   if (p >= in_end) return s;
 #define LW_B(q) ((uint32_t)win[lw_at((q) - w0)])
   if (CODEC == PQD_CODEC_SNAPPY) {
+    // (without branches: the lanes of a wave meet all kinds of elements at once)
     const uint32_t tag = LW_B(p), kind = tag & 3u, n6 = tag >> 2;
     const uint32_t b1 = LW_B(p + 1), b2 = LW_B(p + 2), b3 = LW_B(p + 3), b4 = LW_B(p + 4);
     const uint32_t rest = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
-    if (kind == 0u) {
-      const uint32_t nb = n6 >= 60u ? n6 - 59u : 0u;
-      const uint32_t field = nb == 4u ? rest : rest & ((1u << (8u * nb)) - 1u);
-      const uint64_t len = (uint64_t)(nb ? field : n6) + 1u;
-      const uint64_t end = (uint64_t)p + 1u + nb + len;
-      if (end > in_end) return s;
-      s.lit_len = (uint32_t)len;
-      s.lit_pos = p + 1u + nb;
-      s.next = (uint32_t)end;
-    } else {
-      const uint32_t hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
-      s.mlen = kind == 1u ? 4u + (n6 & 7u) : 1u + n6;
-      s.offset = kind == 1u ? ((tag >> 5) << 8) | b1 : kind == 2u ? rest & 0xFFFFu : rest;
-      if (p + hdr > in_end || s.offset == 0u) return s;
-      s.next = p + hdr;
-    }
-    s.ok = true;
+    const bool lit = kind == 0u;
+    // as a literal: lengths above 60 in 1..4 bytes behind the tag
+    const uint32_t nb = n6 >= 60u ? n6 - 59u : 0u;
+    const uint32_t field = rest & (uint32_t)((1ull << (8u * nb)) - 1ull);
+    const bool field_fine = field < in_end;  // (longer than the stream otherwise; no overflow below)
+    const uint32_t lit_len = (nb ? (field_fine ? field : 0u) : n6) + 1u;
+    // as a copy
+    const uint32_t copy_hdr = kind == 1u ? 2u : kind == 2u ? 3u : 5u;
+    const uint32_t copy_len = kind == 1u ? 4u + (n6 & 7u) : 1u + n6;
+    const uint32_t offset = kind == 1u ? ((tag >> 5) << 8) | b1 : kind == 2u ? rest & 0xFFFFu : rest;
+    s.lit_len = lit ? lit_len : 0u;
+    s.lit_pos = p + 1u + nb;
+    s.mlen = lit ? 0u : copy_len;
+    s.offset = offset;
+    s.next = p + (lit ? 1u + nb + lit_len : copy_hdr);
+    s.ok = s.next <= in_end && (lit ? field_fine : offset != 0u);
   } else {
     const uint32_t token = LW_B(p);
     uint32_t q = p + 1u, lit = token >> 4;
@@ -188,11 +189,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     if (t + 16u <= staged - w0) {
       u32x4 v;
       __builtin_memcpy(&v, (const uint8_t*)(src + w0 + t), 16);
-      uint32_t* d = reinterpret_cast<uint32_t*>(L.win + lw_at(t));  // (a piece never crosses a segment's end)
-      d[0] = v.x;
-      d[1] = v.y;
-      d[2] = v.z;
-      d[3] = v.w;
+      *reinterpret_cast<u32x4*>(L.win + t) = v;
     } else {
       for (uint32_t k = 0; t + k < staged - w0; ++k) L.win[lw_at(t + k)] = src[w0 + t + k];
     }
@@ -200,25 +197,31 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
   __syncthreads();
   LW_STAMP(0)
   if (wave == 0) {
-    // ---- 1. the places of this lane's segment, last to first
+    // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more: neither of
+    // the two continues at the other)
     const uint32_t seg = w0 + lane * 32u;
-    for (int pl = 31; pl >= 0; --pl) {
-      const LwSeq s = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)pl, in_end, staged);
-      uint32_t ex = LW_FAIL, c = 0, made = 0;
-      if (s.ok) {
-        ex = s.next;
-        c = (s.lit_len ? 1u : 0u) + (s.mlen ? 1u : 0u);
-        made = s.lit_len + s.mlen;
-        if (s.next < seg + 32u) {
-          const uint32_t j = s.next - seg;
-          ex = L.u.p.exits[lane * 33u + j];
-          c += L.u.p.counts[lane * 36u + j];
-          made += L.u.p.produce[lane * 33u + j];
-        }
+    for (int pl = 31; pl >= 1; pl -= 2) {
+      LwSeq s[2];
+      uint32_t j[2];
+      u32x2 at_j[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s[u] = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)(pl - u), in_end, staged);
+        s[u].ok = s[u].ok && s[u].lit_len < LW_HUGE && s[u].mlen < LW_HUGE;  // (a segment's sum stays below 2^24)
+        // a sequence that ends inside the segment continues with the entry of the place it ends at (the look-up is made
+        // in any case, at a place inside the segment)
+        j[u] = s[u].ok && s[u].next < seg + 32u ? s[u].next - seg : 31u;
       }
-      L.u.p.exits[lane * 33u + (uint32_t)pl] = ex;
-      L.u.p.counts[lane * 36u + (uint32_t)pl] = (uint8_t)c;
-      L.u.p.produce[lane * 33u + (uint32_t)pl] = made;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) at_j[u] = L.u.p.place[lane * 33u + j[u]];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool inside = s[u].ok && s[u].next < seg + 32u;
+        u32x2 e;
+        e.x = !s[u].ok ? LW_FAIL : inside ? at_j[u].x : s[u].next;
+        e.y = !s[u].ok ? 0u : s[u].lit_len + s[u].mlen + (((s[u].lit_len ? 1u : 0u) + (s[u].mlen ? 1u : 0u)) << 24) + (inside ? at_j[u].y : 0u);
+        L.u.p.place[lane * 33u + (uint32_t)(pl - u)] = e;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     LW_STAMP(1)
@@ -230,15 +233,15 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       uint64_t made = op;
       while (at < w0 + LW_WIN && at < in_end && made <= cap) {
         const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
-        const uint32_t ex = lw_uni(L.u.p.exits[k * 33u + pl]), c = lw_uni(L.u.p.counts[k * 36u + pl]);
-        const uint32_t m = lw_uni(L.u.p.produce[k * 33u + pl]);
+        const u32x2 e = L.u.p.place[k * 33u + pl];
+        const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
         if (lane == k) {
           entry = at;
           first_elem = elems;
           first_out = made;
         }
-        elems += c;
-        made += m;
+        elems += m >> 24;
+        made += m & 0xFFFFFFu;
         if (ex & LW_FAIL) break;
         at = ex;
       }
@@ -253,7 +256,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       uint64_t o = first_out;
       while (q < seg + 32u && q < in_end) {
         const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
-        if (!s.ok || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
+        if (!s.ok || s.lit_len >= LW_HUGE || s.mlen >= LW_HUGE || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
           stop = true;
           break;
         }
