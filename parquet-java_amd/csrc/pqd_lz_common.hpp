@@ -1,12 +1,11 @@
-// What the page decompression kernels share: the input staged in LDS chunk by chunk (InStage) and the
-// output ring with its copy primitives (OutRing).  One wave per page uses them.
+// What the one-wave-per-page kernels share (ZSTD, GZIP, the suffix stream of DELTA_BYTE_ARRAY): the input staged in LDS
+// chunk by chunk (InStage) and an output ring with its copy primitives (OutRing).
 #pragma once
 
 #include "pqd_device.hpp"
 
 namespace pqd {
 
-constexpr uint32_t LZ_RING_DEFAULT = 16384;  // PQD_LZ_RING=8|16|32 (KiB) chooses another size: more pages per CU against more matches read back from memory
 constexpr uint32_t LZ_CHUNK = 2048;
 constexpr uint32_t LZ_STAGE = 2 * LZ_CHUNK;
 

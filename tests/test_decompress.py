@@ -525,14 +525,11 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ring_kib", [None, "8", "32"])
-def test_gpu_snappy_far_copies_in_front_of_literals(orc, monkeypatch, ring_kib):
+def test_gpu_snappy_far_copies_in_front_of_literals(orc):
     import torch
     import parquet_java_amd as pq
     import gpu_harness as gh
     pq.init(0)
-    if ring_kib:
-        monkeypatch.setenv("PQD_LZ_RING", ring_kib)
     stream, raw = handmade_snappy_far_copies()
     assert orc.decompress("SNAPPY", stream, len(raw))[1].tobytes() == raw
     items = [(stream, len(raw))] * 3

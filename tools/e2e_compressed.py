@@ -140,7 +140,8 @@ def main():
                 decode(list(out_table), d_bodies.data_ptr())
 
             def host_flow():
-                codec_obj = pa.Codec(pa_name) if pa_name else None
+                import threading
+                per_thread = threading.local()  # (a codec object is not to be shared between threads)
                 bodies = as_numpy(h_bodies, bodies_cap)
                 unc, at, jobs = [], 0, []
                 for p in pages:
@@ -153,8 +154,10 @@ def main():
                 def one(job):
                     p, to = job
                     src = chunk[p.body_offset:p.body_offset + p.compressed_size]
-                    if codec_obj is not None:
-                        src = codec_obj.decompress(src, decompressed_size=p.uncompressed_size)
+                    if pa_name:
+                        if not hasattr(per_thread, "codec"):
+                            per_thread.codec = pa.Codec(pa_name)
+                        src = per_thread.codec.decompress(src, decompressed_size=p.uncompressed_size)
                     bodies[to:to + p.uncompressed_size] = np.frombuffer(src, np.uint8)
                 if pool is None:
                     for job in jobs:
