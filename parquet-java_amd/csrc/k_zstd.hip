@@ -24,7 +24,10 @@ constexpr uint32_t ZS_RING = 8192;
 constexpr uint32_t ZS_BLOCK_MAX = 128 * 1024;
 
 struct ZShared {
-  uint32_t ll[512], of[256], ml[512];  // FSE entries: symbol | bits << 8 | next-state base << 16
+  // The sequence decoder's entries, one per FSE state: .x = the code's baseline (lengths), .y = bits of the value
+  // behind the baseline | bits of the next state << 8 | next-state base << 16
+  u32x2 ll[512], of[256], ml[512];
+  uint32_t tab32[512];                 // an FSE table as it is built: symbol | bits << 8 | next-state base << 16
   uint16_t huf[2048];                  // Huffman entries: symbol | bits << 8
   int16_t norm[256];
   uint16_t next[256];
@@ -33,6 +36,7 @@ struct ZShared {
   uint32_t log_ll, log_of, log_ml, have_ll, have_of, have_ml, huf_bits, huf_valid;
   uint32_t rep[3];
   int32_t lane_status[4];
+  uint32_t ll_code[36], ml_code[53];  // baseline | extra bits << 24 of the length codes (read per sequence: LDS, not memory)
 };
 
 __device__ const int16_t Z_LL_DEFAULT[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
@@ -296,88 +300,82 @@ __device__ __forceinline__ int32_t zhuf_stream(const ZShared& sh, const PQD_GLOB
   return bit == 0 ? PQD_OK : PQD_DECODE;
 }
 
-// The sequences' bit stream, read backwards: the region [p0, p0 + n) of the input is staged 4 KiB at a time in
-// LDS; 64 bits are fetched at once and fields taken from them.
-struct BackBits {
-  const PQD_GLOBAL uint8_t* base;  // input base (16-byte aligned); positions count from it
-  uint32_t p0, n;
-  uint8_t* lds;
-  int64_t bit;       // bits not yet read
-  int32_t win_chunk;  // chunks win_chunk and win_chunk + 1 of the region are staged (chunk = 2 KiB of the region); INT_MIN: none
-  uint64_t cache;
-  int64_t cache_lo;
+// The sequences' bit stream, read backwards.  The lanes hold 64 aligned words of the input around the reading
+// position (lane l: word `base` + l), and the 64 below them with four words in common, requested when the upper ones
+// come into use: a field is two lane reads and a shift, nothing waits for memory or LDS.  Bit positions count from the
+// first bit of the word that holds the region's first byte.
+struct BackWords {
+  const PQD_GLOBAL uint32_t* words;  // the input from its 16-byte aligned base
+  int32_t n_words;                   // words that hold bytes of the input
+  int32_t w0;                        // the word of the region's first byte
+  int32_t base;
+  uint32_t cur, nxt;
   uint32_t lane;
 
-  __device__ __forceinline__ void stage(int32_t c) {
-    __syncthreads();
-    for (uint32_t k = 0; k < 4; ++k) {
-      const int64_t rpos = (int64_t)c * LZ_CHUNK + (int64_t)(k * 1024u + lane * 16u);  // region position of this lane's 16 bytes
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (rpos >= 0 && rpos + 16 <= (int64_t)n) {
-        __builtin_memcpy(&v, base + p0 + (uint32_t)rpos, 16);
-      } else if (rpos + 16 > 0 && rpos < (int64_t)n) {
-        uint32_t tmp[4] = {0u, 0u, 0u, 0u};
-        for (int b = 0; b < 16; ++b) {
-          const int64_t q = rpos + b;
-          if (q >= 0 && q < (int64_t)n) tmp[b >> 2] |= (uint32_t)base[p0 + (uint32_t)q] << (8 * (b & 3));
-        }
-        v = u32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
-      }
-      *reinterpret_cast<u32x4*>(lds + k * 1024u + lane * 16u) = v;
-    }
-    win_chunk = c;
-    __syncthreads();
+  __device__ __forceinline__ uint32_t load(int32_t b) const {
+    const int32_t w = w0 + b + (int32_t)lane;
+    return w >= 0 && w < n_words ? words[w] : 0u;
   }
-  // 64 bits whose lowest is region bit 8 * byte0 (byte0 may be negative)
-  __device__ __forceinline__ uint64_t fetch(int64_t byte0) {
-    const int32_t c = (int32_t)((byte0 + 7) >> 11) - 1;  // the 8 bytes lie in chunks c, c + 1
-    if (c != win_chunk) stage(c);
-    const uint32_t off = (uint32_t)(byte0 - (int64_t)c * LZ_CHUNK);  // 0 .. 4088
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
-    const uint32_t i0 = off >> 2, sh = (off & 3u) * 8u;
-    const uint32_t d0 = uni(w[i0]), d1 = uni(w[i0 + 1]), d2 = uni(w[(i0 + 2) & (LZ_STAGE / 4 - 1)]);
-    const uint32_t lo = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0, hi = sh ? (d1 >> sh) | (d2 << (32u - sh)) : d1;
-    return ((uint64_t)hi << 32) | lo;
+  __device__ __forceinline__ void start(int32_t bitpos) {
+    base = (bitpos >> 5) - 63;
+    cur = load(base);
+    nxt = load(base - 60);
   }
-  __device__ __forceinline__ uint32_t read(uint32_t k) {  // k <= 32
-    if (k == 0) return 0;
-    bit -= (int64_t)k;
-    if (bit < cache_lo) {
-      const int64_t byte0 = (bit + (int64_t)k - 64 + 7) >> 3;  // the cache ends at or above the field's top
-      cache_lo = byte0 * 8;
-      cache = fetch(byte0);
+  // before a sequence is read at `bitpos`: its fields are 89 bits at most
+  __device__ __forceinline__ void need(int32_t bitpos) {
+    if ((bitpos >> 5) - 3 < base) {
+      base -= 60;
+      cur = nxt;
+      nxt = load(base - 60);
     }
-    return (uint32_t)(cache >> (bit - cache_lo)) & (k == 32 ? 0xFFFFFFFFu : (1u << k) - 1u);
+  }
+  // the k <= 32 bits from bit `lo` up
+  __device__ __forceinline__ uint32_t field(int32_t lo, uint32_t k) const {
+    const uint32_t w = (uint32_t)((lo >> 5) - base);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)w);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(w < 63u ? w + 1u : 63u));
+    return (uint32_t)((((uint64_t)b << 32) | a) >> ((uint32_t)lo & 31u)) & (uint32_t)((1ull << k) - 1ull);
   }
 };
 
-// one table of the sequences section; returns bytes used or ~0u
-__device__ __forceinline__ uint32_t zseq_table(ZShared& sh, InStage& in, uint32_t* tab, uint32_t& tlog, uint32_t& have, uint32_t mode, uint32_t p0,
-                               uint32_t n, const PQD_GLOBAL int16_t* def, uint32_t def_n, uint32_t def_log, uint32_t max_sym, uint32_t max_log) {
+// one table of the sequences section (kind 0: literal lengths, 1: offsets, 2: match lengths); returns bytes used or ~0u
+__device__ __forceinline__ uint32_t zseq_table(ZShared& sh, InStage& in, u32x2* tab, uint32_t kind, uint32_t& tlog, uint32_t& have, uint32_t mode,
+                               uint32_t p0, uint32_t n, const PQD_GLOBAL int16_t* def, uint32_t def_n, uint32_t def_log, uint32_t max_sym,
+                               uint32_t max_log) {
   if (mode == 3) return have ? 0u : ~0u;  // repeat
+  uint32_t used, log;
   if (mode == 1) {  // one symbol, no bits
     if (n < 1) return ~0u;
     const uint32_t s = zbyte(in, p0);
     if (s > max_sym) return ~0u;
-    tab[0] = s;
-    tlog = 0;
-    have = 1;
     __syncthreads();
-    return 1;
-  }
-  uint32_t n_sym = def_n, log = def_log, used = 0;
-  if (mode == 0) {
-    for (uint32_t i = 0; i < def_n; ++i) sh.norm[i] = def[i];
+    sh.tab32[0] = s;
+    log = 0;
+    used = 1;
   } else {
-    used = zfse_norm(in, p0, n, sh.norm, n_sym, max_sym, log, max_log);
-    if (used == ~0u) return ~0u;
+    uint32_t n_sym = def_n;
+    log = def_log;
+    used = 0;
+    if (mode == 0) {
+      for (uint32_t i = 0; i < def_n; ++i) sh.norm[i] = def[i];
+    } else {
+      used = zfse_norm(in, p0, n, sh.norm, n_sym, max_sym, log, max_log);
+      if (used == ~0u) return ~0u;
+    }
+    __syncthreads();
+    if (!zfse_build(sh.tab32, sh.norm, sh.next, n_sym, log)) return ~0u;
   }
   __syncthreads();
-  if (!zfse_build(tab, sh.norm, sh.next, n_sym, log)) return ~0u;
+  // (symbols are max_sym at most: the description cannot hold more)
+  for (uint32_t u = in.lane; u < (1u << log); u += 64u) {
+    const uint32_t e = sh.tab32[u], sym = e & 0xFFu;
+    const uint32_t code = kind == 1u ? sym << 24 : kind == 0u ? sh.ll_code[sym] : sh.ml_code[sym];
+    tab[u] = u32x2{code & 0xFFFFFFu, (e & 0xFFFFFF00u) | (code >> 24)};
+  }
+  __syncthreads();
   tlog = log;
   have = 1;
   return used;
-
 }
 
 // XXH64 of n bytes this wave stored at p (the frame's content checksum is its low 32 bits): the four
@@ -443,7 +441,6 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZS_RING];
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
   __shared__ __attribute__((aligned(16))) uint8_t s_lits[LZ_STAGE];
-  __shared__ __attribute__((aligned(16))) uint8_t s_back[LZ_STAGE];
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
@@ -456,6 +453,8 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
     }
     return;
   }
+  if (lane < 36u) sh.ll_code[lane] = Z_LL_BASE[lane] | ((uint32_t)Z_LL_BITS[lane] << 24);
+  if (lane < 53u) sh.ml_code[lane] = Z_ML_BASE[lane] | ((uint32_t)Z_ML_BITS[lane] << 24);
   InStage in;
   in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
   const uint32_t skew = (uint32_t)((uintptr_t)d.src & 15u);
@@ -752,11 +751,11 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           }
           uint32_t used = 0;
           for (uint32_t t = 0; t < 3u && used != ~0u; ++t) {  // literal lengths, offsets, match lengths
-            uint32_t* tab = t == 0 ? sh.ll : t == 1 ? sh.of : sh.ml;
+            u32x2* tab = t == 0 ? sh.ll : t == 1 ? sh.of : sh.ml;
             uint32_t& tlog = t == 0 ? sh.log_ll : t == 1 ? sh.log_of : sh.log_ml;
             uint32_t& have = t == 0 ? sh.have_ll : t == 1 ? sh.have_of : sh.have_ml;
             const PQD_GLOBAL int16_t* def = (const PQD_GLOBAL int16_t*)(t == 0 ? Z_LL_DEFAULT : t == 1 ? Z_OF_DEFAULT : Z_ML_DEFAULT);
-            used = zseq_table(sh, in, tab, tlog, have, (modes >> (6u - 2u * t)) & 3u, p + pos, size - pos, def,
+            used = zseq_table(sh, in, tab, t, tlog, have, (modes >> (6u - 2u * t)) & 3u, p + pos, size - pos, def,
                               t == 0 ? 36u : t == 1 ? 29u : 53u, t == 1 ? 5u : 6u, t == 0 ? 35u : t == 1 ? 31u : 52u, t == 1 ? 8u : 9u);
             if (used != ~0u) pos += used;
           }
@@ -775,35 +774,57 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             status = PQD_DECODE;
             break;
           }
-          BackBits bb;
-          bb.base = in.base;
-          bb.p0 = p + pos;
-          bb.n = sn;
-          bb.lds = s_back;
+          BackWords bb;
+          bb.words = (const PQD_GLOBAL uint32_t*)in.base;
+          bb.n_words = (int32_t)((in_end + 3u) >> 2);
+          bb.w0 = (int32_t)((p + pos) >> 2);
           bb.lane = lane;
-          bb.win_chunk = (int32_t)0x80000000;
-          bb.bit = (int64_t)(sn - 1) * 8 + (int64_t)zhighbit(last_byte);
-          bb.cache = 0;
-          bb.cache_lo = bb.bit + 1;
+          // bits not yet read, counted from the first bit of word w0
+          int32_t bit = (int32_t)(((p + pos) & 3u) * 8u + (sn - 1u) * 8u + zhighbit(last_byte));
+          const int32_t bit_end = (int32_t)(((p + pos) & 3u) * 8u);
+          bb.start(bit);
           const uint32_t log_ll = uni(sh.log_ll), log_of = uni(sh.log_of), log_ml = uni(sh.log_ml);
-          uint32_t sl = bb.read(log_ll), so = bb.read(log_of), sm = bb.read(log_ml);
+          bit -= (int32_t)log_ll;
+          uint32_t sl = bb.field(bit, log_ll);
+          bit -= (int32_t)log_of;
+          uint32_t so = bb.field(bit, log_of);
+          bit -= (int32_t)log_ml;
+          uint32_t sm = bb.field(bit, log_ml);
+          if (bit < bit_end) {
+            status = PQD_DECODE;
+            break;
+          }
           uint32_t rep0 = uni(sh.rep[0]), rep1 = uni(sh.rep[1]), rep2 = uni(sh.rep[2]);
+          u32x2 eo = sh.of[so], em = sh.ml[sm], el = sh.ll[sl];
+#ifdef ZS_PROF
+          uint64_t zp[3] = {0, 0, 0}, zt = __builtin_readcyclecounter();
+#define ZS_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); zp[k] += now_ - zt; zt = now_; }
+#else
+#define ZS_STAMP(k)
+#endif
           for (uint32_t i = 0; i < n_seq; ++i) {
-            const uint32_t eo = uni(sh.of[so]), em = uni(sh.ml[sm]), el = uni(sh.ll[sl]);
-            const uint32_t oc = eo & 0xFFu, mc = em & 0xFFu, lc = el & 0xFFu;
-            if (oc > 31u || mc > 52u || lc > 35u) {
-              status = PQD_DECODE;
-              break;
-            }
-            const uint64_t ov = (1ull << oc) + bb.read(oc);
-            const uint32_t ml = Z_ML_BASE[mc] + bb.read(Z_ML_BITS[mc]);
-            const uint32_t ll = Z_LL_BASE[lc] + bb.read(Z_LL_BITS[lc]);
+            bb.need(bit);
+            // where the six fields lie follows from the three entries alone
+            const uint32_t oy = uni(eo.y), my = uni(em.y), ly = uni(el.y), m_base = uni(em.x), l_base = uni(el.x);
+            const uint32_t ob = oy & 0xFFu, mb = my & 0xFFu, lb = ly & 0xFFu;
+            const int32_t at_o = bit - (int32_t)ob, at_m = at_o - (int32_t)mb, at_l = at_m - (int32_t)lb;
+            const uint32_t ov = (1u << ob) + bb.field(at_o, ob);
+            const uint32_t ml = m_base + bb.field(at_m, mb);
+            const uint32_t ll = l_base + bb.field(at_l, lb);
+            bit = at_l;
             if (i + 1 < n_seq) {
-              sl = (el >> 16) + bb.read((el >> 8) & 0xFFu);
-              sm = (em >> 16) + bb.read((em >> 8) & 0xFFu);
-              so = (eo >> 16) + bb.read((eo >> 8) & 0xFFu);
+              const uint32_t nl = (ly >> 8) & 0xFFu, nm = (my >> 8) & 0xFFu, no = (oy >> 8) & 0xFFu;
+              const int32_t at_sl = at_l - (int32_t)nl, at_sm = at_sl - (int32_t)nm, at_so = at_sm - (int32_t)no;
+              sl = (ly >> 16) + bb.field(at_sl, nl);
+              sm = (my >> 16) + bb.field(at_sm, nm);
+              so = (oy >> 16) + bb.field(at_so, no);
+              bit = at_so;
+              // (the next sequence's entries are on their way while this one's bytes are moved)
+              eo = sh.of[so];
+              em = sh.ml[sm];
+              el = sh.ll[sl];
             }
-            if (bb.bit < 0) {
+            if (bit < bit_end) {
               status = PQD_DECODE;
               break;
             }
@@ -814,7 +835,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               rep1 = rep0;
               rep0 = offset;
             } else {
-              const uint32_t idx = (uint32_t)ov - 1u + (ll == 0 ? 1u : 0u);
+              const uint32_t idx = ov - 1u + (ll == 0 ? 1u : 0u);
               if (idx == 0) {
                 offset = rep0;
               } else {
@@ -828,7 +849,9 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               status = PQD_DECODE;
               break;
             }
+            ZS_STAMP(0)
             put_literals(ll);
+            ZS_STAMP(1)
             // matches reach back into the frame only
             if (offset == 0u || offset > op - frame_start || ml > cap - op) {
               status = PQD_DECODE;
@@ -836,14 +859,18 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             }
             out.match(op, offset, ml);
             op += ml;
+            ZS_STAMP(2)
           }
+#ifdef ZS_PROF
+          if (page == 0 && lane == 0) printf("block: %u sequences, cycles per sequence: decode %llu, literals %llu, match %llu\n", n_seq, zp[0] / n_seq, zp[1] / n_seq, zp[2] / n_seq);
+#endif
           __syncthreads();
           sh.rep[0] = rep0;
           sh.rep[1] = rep1;
           sh.rep[2] = rep2;
           __syncthreads();
           if (status != PQD_OK) break;
-          if (bb.bit != 0) {
+          if (bit != bit_end) {
             status = PQD_DECODE;
             break;
           }
