@@ -333,6 +333,51 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
   }
 }
 
+// Long pages of many short runs (a million values in 25000 runs), marked PLAN_F_LONG by the plan kernel: the whole-page
+// routine in its long shape, a workgroup of sixteen waves per page.  What it cannot take goes to the left-over launch.
+template <int ELEM, bool HAS_DICT>
+__global__ __launch_bounds__(WpLong::THREADS) void k_whole_long_pages(const pqd_page_desc* __restrict__ descs,
+                                                                      pqd_page_result* __restrict__ results,
+                                                                      RlePagePlan* __restrict__ plans, uint32_t* __restrict__ cursor,
+                                                                      uint32_t n_pages) {
+  extern __shared__ u32x4 long_lds[];
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  if ((uint32_t)__builtin_amdgcn_readfirstlane((int)plans[page].flags) != PLAN_F_LONG) return;
+  const pqd_page_desc d = descs[page];
+  const bool done = dict_whole_page<ELEM, !HAS_DICT, WpLong>(d, results + page, *reinterpret_cast<WholePageLdsT<WpLong>*>(long_lds));
+  if (threadIdx.x == 0) {
+    plans[page].flags = done ? PLAN_F_DONE : PLAN_F_FALLBACK;
+    if (!done) cursor[PLAN_CTR_FALLBACK] = 1u;
+  }
+}
+
+hipError_t launch_whole_long_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t* cursor, uint32_t n_pages,
+                                   bool has_dict, int elem, hipStream_t stream) {
+  if (n_pages == 0) return hipSuccess;
+  constexpr uint32_t LDS = (uint32_t)sizeof(WholePageLdsT<WpLong>);
+  static_assert(LDS <= 160u * 1024u, "one workgroup's LDS");
+  const void* fn = !has_dict ? reinterpret_cast<const void*>(k_whole_long_pages<4, false>)
+                             : elem == 4 ? reinterpret_cast<const void*>(k_whole_long_pages<4, true>)
+                                         : reinterpret_cast<const void*>(k_whole_long_pages<8, true>);
+  static bool attr_set[3] = {false, false, false};  // (set again by a second thread at worst: the call is idempotent)
+  const int which = !has_dict ? 0 : elem == 4 ? 1 : 2;
+  if (!attr_set[which]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return e;
+    attr_set[which] = true;
+  }
+  RlePagePlan* pl = reinterpret_cast<RlePagePlan*>(plans);
+  const dim3 grid(n_pages), block(WpLong::THREADS);
+  if (!has_dict)
+    hipLaunchKernelGGL((k_whole_long_pages<4, false>), grid, block, LDS, stream, descs, results, pl, cursor, n_pages);
+  else if (elem == 4)
+    hipLaunchKernelGGL((k_whole_long_pages<4, true>), grid, block, LDS, stream, descs, results, pl, cursor, n_pages);
+  else
+    hipLaunchKernelGGL((k_whole_long_pages<8, true>), grid, block, LDS, stream, descs, results, pl, cursor, n_pages);
+  return hipGetLastError();
+}
+
 hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results, uint32_t n_pages, int elem,
                             bool has_dict, const void* only_fallback_plans, const uint32_t* fallback_count,
                             hipStream_t stream, const void* pool, uint32_t pool_chunks, const uint32_t* cursor, uint32_t* zero,

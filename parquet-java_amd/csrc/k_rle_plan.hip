@@ -545,7 +545,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
                                                                   uint32_t pool_chunks, uint32_t* __restrict__ cursor,
                                                                   uint32_t n_pages, int want_dict, int elem,
                                                                   DictPlanes planes, int small_ran, uint32_t direct_max,
-                                                                  uint32_t whole_max) {
+                                                                  uint32_t whole_max, int long_ok) {
   __shared__ u32x4 win4[PLAN_SLOTS + 1];
   __shared__ RleSeg stage[SEG_CHUNK];
   __shared__ RleSeg chunk[SEG_CHUNK];
@@ -642,6 +642,15 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
   }
   // Run-heavy dictionary pages (a short stream for their number of values) are not planned at all: the left-over launch
   // decodes them whole, ids and lookups in one pass (pqd_whole_page.hpp), and falls back to its page decoder by itself.
+  // Long pages of many short runs, when the launch sequence has the kernel for them (few pages in the call: a
+  // workgroup of sixteen waves per page then has a CU to itself): one wave planning 25000 runs is what such a call waits for.
+  if (long_ok && (!want_dict || d.dict != nullptr) && whole_page_long_candidate(end - pos, n_values, w, want_dict ? d.dict_len : 1u, whole_max)) {
+    if (tid == 0) {
+      plans[page].flags = PLAN_F_LONG;
+      if (page < pool_chunks) write_empty_chunk(pool, page);
+    }
+    return;
+  }
   if (want_dict && d.dict != nullptr && whole_page_candidate(end - pos, n_values, w, d.dict_len, whole_max)) {
     if (tid == 0) {
       plans[page].flags = PLAN_F_WHOLE;
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
 
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
-                                  const DictPlanes& planes, bool try_small, hipStream_t stream) {
+                                  const DictPlanes& planes, bool try_small, hipStream_t stream, bool long_ok) {
   if (n_pages == 0) return hipSuccess;
   if (want_dict && elem == 8 && planes.n_slots != 0)
     hipLaunchKernelGGL(k_dict_slots, dim3((n_pages + 255u) / 256u), dim3(256), 0, stream, descs, n_pages, cursor, planes);
@@ -1120,8 +1129,10 @@ hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* r
   }
   hipLaunchKernelGGL(k_rle_plan_chunks, dim3(n_pages), dim3(PLAN_THREADS), 0, stream, descs, results,
                      reinterpret_cast<RlePagePlan*>(plans), reinterpret_cast<RleSeg*>(pool), pool_chunks, cursor, n_pages,
-                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0, direct_max, whole_max);
-  return hipGetLastError();
+                     want_dict ? 1 : 0, elem, planes, small ? 1 : 0, direct_max, whole_max, long_ok ? 1 : 0);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !long_ok) return e;
+  return launch_whole_long_pages(descs, results, plans, cursor, n_pages, want_dict, elem, stream);
 }
 
 }  // namespace pqd

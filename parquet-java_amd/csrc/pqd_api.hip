@@ -649,7 +649,8 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         uint32_t *counters, *other;
         if ((st = counters_begin(ps, s, &counters, &other))) return st;
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, counters, n_pages, false, 4,
-                                            pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, use_small_rle_kernel(), s));
+                                            pqd::DictPlanes{nullptr, nullptr, nullptr, 0u}, use_small_rle_kernel(), s,
+                                            n_pages <= pqd::WP_LONG_MAX_PAGES));
         PQD_HIP(pqd::launch_rle_expand(ps.gen_pool, pool_chunks, counters, n_pages, s));
         PQD_HIP(pqd::launch_rle_pages(descs, results, n_pages, 4, false, ps.plans, counters + 1, s, nullptr, 0, nullptr, other, COUNTER_ZERO_WORDS));
         counters_end(ps);
@@ -676,7 +677,7 @@ int pqd_decode_pages_dev(const pqd_page_desc* descs, pqd_page_result* results, u
         if ((st = phase_mark(0, s))) return st;
         const uint32_t pool_chunks = usable_pool_chunks(ps.gen_chunks);
         PQD_HIP(pqd::launch_rle_plan_chunks(descs, results, ps.plans, ps.gen_pool, pool_chunks, counters, n_pages, true,
-                                            elem_size, planes, false, s));
+                                            elem_size, planes, false, s, n_pages <= pqd::WP_LONG_MAX_PAGES));
         if ((st = phase_mark(1, s))) return st;
         // (the sliced gather takes the page slots and the front half of the pool's tail; the back half holds the
         // chunks that the left-over launch expands)

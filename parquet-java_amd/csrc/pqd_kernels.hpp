@@ -30,7 +30,12 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
 // (dictionary pages of 8-byte values: `planes` is where dictionaries that need plane copies get their slot)
 hipError_t launch_rle_plan_chunks(const pqd_page_desc* descs, pqd_page_result* results, void* plans, void* pool,
                                   uint32_t pool_chunks, uint32_t* cursor, uint32_t n_pages, bool want_dict, int elem,
-                                  const DictPlanes& planes, bool try_small, hipStream_t stream);
+                                  const DictPlanes& planes, bool try_small, hipStream_t stream, bool long_ok = false);
+// Long pages of many short runs that the plan kernel marked PLAN_F_LONG (launch_rle_plan_chunks with long_ok calls it):
+// a workgroup of 1024 threads per page; a page it gives up is marked for the left-over launch.
+constexpr uint32_t WP_LONG_MAX_PAGES = 1024;  // calls of at most that many pages get the launch
+hipError_t launch_whole_long_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t* cursor, uint32_t n_pages,
+                                   bool has_dict, int elem, hipStream_t stream);
 // small plain hybrid pages (stream <= 8 KiB, <= 32768 values, widths 1..24) decoded whole; sets plans[page].flags
 // for every page (PLAN_F_SMALL_DONE where it decoded the page)
 hipError_t launch_rle_small_pages(const pqd_page_desc* descs, pqd_page_result* results, void* plans, uint32_t n_pages,

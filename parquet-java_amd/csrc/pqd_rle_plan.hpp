@@ -98,6 +98,7 @@ constexpr uint32_t PLAN_COUNTER_BYTES = (PLAN_CTR_LIST0 + PLAN_IRREGULAR_LIST) *
 constexpr uint32_t PLAN_F_DONE = 1u;      // result already written by the plan kernel (empty / rejected page)
 constexpr uint32_t PLAN_F_SMALL_DONE = 4u;  // decoded by k_rle_small_pages before the plan kernel ran (which turns it into PLAN_F_DONE)
 constexpr uint32_t PLAN_F_WHOLE = 8u;     // a run-heavy dictionary page left unplanned: decoded whole by the left-over launch (pqd_whole_page.hpp)
+constexpr uint32_t PLAN_F_LONG = 16u;     // a long page of many short runs, left unplanned: decoded by k_whole_long_pages (which marks what it gives up PLAN_F_FALLBACK)
 constexpr uint32_t PLAN_F_FALLBACK = 2u;  // not for the planned kernels (too many segments, dictionary not sweepable): generic kernel
 
 // Sliced dictionary gather: LDS slice size and the values one workgroup holds in registers per

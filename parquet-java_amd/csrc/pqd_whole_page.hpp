@@ -10,9 +10,12 @@
 // 64-byte block leaves it, one thread hops over the blocks, every thread lists the runs of its block; a run table and a
 // bitmap of run starts then give every value its run by a popcount.  The dictionary is read from memory (L2): the ids of
 // such a page are few and close together.
-// Covered: streams of at most 32 KiB (taken through LDS a window of 8 KiB at a time) that are at most half of what the
-// page's values would take bit-packed, at most 32768 values, id widths 1..24, run headers of up to three bytes, runs
-// shorter than a window.  Anything else, and every malformed stream (zero-length
+// Covered: streams that are at most half of what the page's values would take bit-packed (taken through LDS a window of
+// 8 KiB and 32768 values at a time: a window ends in front of the first run that does not fit, or inside an RLE run,
+// whose remaining values are then stored without a window), id widths 1..24, run headers of up to three bytes, bit-packed
+// runs shorter than a window.  Small pages (32 KiB of stream, 32768 values) of dictionary ids are sent here by the plan
+// kernel because a plan costs them more; long pages of many short runs (a million values in 25000 runs) because one wave
+// planning them run by run is the slowest part of their launch.  Anything else, and every malformed stream (zero-length
 // runs, runs cut off by the end of the stream, a stream that ends short of the page's values), returns false: the
 // caller decodes the page (again, where windows had been written) with the kernel that knows every rule of the reference.
 // Traffic: stream bytes in, ELEM bytes out per value; the dictionary entries come from L2.
@@ -32,19 +35,42 @@ constexpr uint32_t WP_BLOCKS = WP_MAX_BYTES / WP_BLOCK;
 constexpr uint32_t WP_MAX_VALUES = 32768;
 constexpr uint32_t WP_MAX_WIDTH = 24;
 constexpr uint32_t WP_COMPLEX = 0xFFFFu, WP_END = 0xFFFEu, WP_STOP = 0xFFFDu;  // (above every stream position of a window)
-constexpr uint32_t WP_BIAS = 1u << 20;  // above first value * w (< 2^15 * 24)
-static_assert(WP_BLOCKS <= WP_THREADS, "a thread per block");
 
-struct alignas(16) WholePageLds {
-  uint8_t pg[WP_MAX_BYTES + 96];    // the stream, zeros behind it
-  uint16_t tab[WP_MAX_BYTES + 64];  // where a chain entering at each byte leaves its block; later the run table (as words)
-  uint32_t flags[WP_MAX_VALUES / 32 + 4];  // bit v: a run starts at value v
-  uint16_t wbase[WP_MAX_VALUES / 64 + 4];  // run starts before each 64-bit word of the bitmap
-  uint16_t entry_of[WP_BLOCKS];            // where the chain enters each block
-  uint32_t wave_totals[WP_THREADS / 64];
-  uint32_t ok, consumed, oob_at, rle_oob, n_eff;
+// The two shapes of the routine: a workgroup of 256 threads with windows of 8 KiB and 32768 values (five of them fit a
+// CU: thousands of small pages), and one of 1024 threads with windows of 16 KiB and 262144 values that has a CU to
+// itself (a launch of few long pages: sixteen waves hide each other's LDS round trips, and the chain through a window
+// is followed 256 bytes at a hop).
+struct WpSmall {
+  static constexpr int THREADS = WP_THREADS;
+  static constexpr uint32_t BYTES = WP_MAX_BYTES, VALUES = WP_MAX_VALUES, VAL_RUNS = 1360, BIAS = 1u << 20;  // BIAS: above first value * w
+  static constexpr bool SUPER = false;
 };
-static_assert((WP_MAX_BYTES / 2) * 4 <= sizeof(uint16_t) * (WP_MAX_BYTES + 64), "the run table fits where the exits were");
+struct WpLong {
+  static constexpr int THREADS = 1024;
+  static constexpr uint32_t BYTES = 16384, VALUES = 262144, VAL_RUNS = 2728, BIAS = 1u << 23;
+  static constexpr bool SUPER = true;
+};
+constexpr uint32_t WP_SUPER = 256;  // bytes per hop of the chain where SUPER is set
+
+template <class C>
+struct alignas(16) WholePageLdsT {
+  uint8_t pg[C::BYTES + 96];    // the stream, zeros behind it
+  uint16_t tab[C::BYTES + 64];  // where a chain entering at each byte leaves its block; later the run table (as words)
+  uint16_t tab2[C::SUPER ? C::BYTES + 64 : 8];  // ... leaves its 256 bytes
+  uint32_t flags[C::VALUES / 32 + 4];  // bit v: a run starts at value v
+  uint16_t wbase[C::VALUES / 64 + 4];  // run starts before each 64-bit word of the bitmap
+  uint16_t entry_of[C::BYTES / WP_BLOCK];  // where the chain enters each block
+  uint16_t sentry[C::BYTES / WP_SUPER + 1];  // ... each 256 bytes
+  uint32_t wave_totals[C::THREADS / 64];
+  uint32_t ok, consumed, oob_at, rle_oob, n_eff;
+  uint32_t cut_at, cut_nv, carry_n, carry_val;  // a window that ends at its last value: where the next one starts
+  static_assert(C::BYTES / WP_BLOCK <= (uint32_t)C::THREADS, "a thread per block");
+  static_assert((C::BYTES / 2) * 4 <= sizeof(uint16_t) * (C::BYTES + 64), "the run table fits where the exits were");
+  static_assert(C::VAL_RUNS * 12u <= sizeof(uint16_t) * (C::BYTES + 64) && (C::VAL_RUNS * 4u) % 8u == 0, "table and values fit where the exits were");
+  static_assert((uint64_t)C::VALUES * 24u < C::BIAS && C::BIAS + C::BYTES * 8u < (1u << 31), "an entry holds the biased bit position");
+  static_assert(C::BYTES + 64 < 0xFFFDu, "positions stay below the marks");
+};
+using WholePageLds = WholePageLdsT<WpSmall>;
 
 // Pages the plan kernel leaves to dict_whole_page (max_bytes: the launch's limit, at most WP_MAX_STREAM; 0: none).
 __host__ __device__ inline bool whole_page_candidate(uint32_t stream_bytes, uint32_t n_values, uint32_t w, uint32_t dict_len,
@@ -52,6 +78,44 @@ __host__ __device__ inline bool whole_page_candidate(uint32_t stream_bytes, uint
   return w >= 1u && w <= WP_MAX_WIDTH && n_values != 0u && n_values <= WP_MAX_VALUES && stream_bytes != 0u &&
          stream_bytes <= max_bytes && stream_bytes <= WP_MAX_STREAM && dict_len != 0u &&
          (uint64_t)stream_bytes * 16u <= (uint64_t)n_values * w;
+}
+// Long run-heavy pages: more values or stream bytes than the rule above takes, and runs of fewer than 64 values on
+// average (pages of longer runs are planned quickly, and their expansion is the faster one).
+constexpr uint32_t WP_LONG_MAX_VALUES = 1u << 30;
+__host__ __device__ inline bool whole_page_long_candidate(uint32_t stream_bytes, uint32_t n_values, uint32_t w, uint32_t dict_len,
+                                                          uint32_t max_bytes) {
+  return max_bytes != 0u && w >= 1u && w <= WP_MAX_WIDTH && n_values <= WP_LONG_MAX_VALUES && dict_len != 0u &&
+         (n_values > WP_MAX_VALUES || stream_bytes > WP_MAX_STREAM) && (uint64_t)stream_bytes * 16u <= (uint64_t)n_values * w &&
+         (uint64_t)stream_bytes * 32u >= (uint64_t)n_values;
+}
+
+// The stream of a page and what stands in front of it (RunLengthBitPackingHybridValuesReader.java:41-45: four bytes of
+// length; DictionaryValuesReader.java:49-63: a byte of width; levels of V2 pages and booleans: nothing).
+struct WholeStream {
+  const PQD_GLOBAL uint8_t* src;
+  uint32_t n, w, prefix;
+  uint32_t consumed_all;  // != ~0u: what the page reports as consumed whatever the runs take (the length prefix says it)
+  bool ok;
+};
+__device__ __forceinline__ WholeStream whole_stream_of(const pqd_page_desc& d, bool has_dict) {
+  WholeStream s = {(const PQD_GLOBAL uint8_t*)d.data, d.data_len, d.bit_width, 0u, ~0u, d.data != nullptr};
+  if (has_dict || (d.flags & PQD_F_WIDTH_PREFIX)) {
+    s.ok = s.ok && d.data_len >= 2u;
+    if (s.ok) s.w = s.src[0];
+    s.prefix = 1u;
+  } else if (d.flags & PQD_F_LENGTH_PREFIX) {
+    s.ok = s.ok && d.data_len >= 4u;
+    uint32_t len = 0;
+    if (s.ok) len = (uint32_t)s.src[0] | ((uint32_t)s.src[1] << 8) | ((uint32_t)s.src[2] << 16) | ((uint32_t)s.src[3] << 24);
+    s.ok = s.ok && (int32_t)len >= 0 && len <= d.data_len - 4u;
+    s.prefix = 4u;
+    s.n = 4u + len;
+    s.consumed_all = 4u + len;
+  }
+  s.ok = s.ok && s.n > s.prefix;
+  s.src += s.prefix;
+  s.n = s.ok ? s.n - s.prefix : 0u;
+  return s;
 }
 
 struct WholeRun {
@@ -75,6 +139,7 @@ __device__ __forceinline__ WholeRun whole_run(uint32_t lo, uint32_t w, uint32_t 
 }
 
 // Exclusive prefix of `v` over the workgroup's threads and the total.
+template <int THREADS>
 __device__ __forceinline__ uint32_t wp_exclusive(uint32_t v, uint32_t* wave_totals, uint32_t& total) {
   const uint32_t inc = wave_scan_inclusive(v);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -84,7 +149,7 @@ __device__ __forceinline__ uint32_t wp_exclusive(uint32_t v, uint32_t* wave_tota
   uint32_t before = 0;
   total = 0;
 #pragma unroll
-  for (uint32_t k = 0; k < WP_THREADS / 64; ++k) {
+  for (uint32_t k = 0; k < (uint32_t)THREADS / 64u; ++k) {
     const uint32_t t = wave_totals[k];
     before += k < wave ? t : 0u;
     total += t;
@@ -92,17 +157,15 @@ __device__ __forceinline__ uint32_t wp_exclusive(uint32_t v, uint32_t* wave_tota
   return before + inc - v;
 }
 
-// Where the looked-up values of the RLE runs sit when the page has at most WP_VAL_RUNS runs: behind that many table
-// entries, in the space the block exits used.
-constexpr uint32_t WP_VAL_RUNS = 1360;
-static_assert(WP_VAL_RUNS * 12u <= sizeof(uint16_t) * (WP_MAX_BYTES + 64) && (WP_VAL_RUNS * 4u) % 8u == 0, "table and values fit where the exits were");
+// (Where the looked-up values of the RLE runs sit when a window has at most VAL_RUNS runs: behind that many table
+// entries, in the space the block exits used.)
 
 // The dictionary entries of values v0 .. v0 + 3 of the window (v0 a multiple of four below n_values, the window's number of
 // values; v_base: the page's values before the window); x[k].y is
 // meaningless for 4-byte dictionaries.  FAST: the entries of RLE runs were looked up once per run and are read from
 // LDS; only values of bit-packed groups are fetched from the dictionary.
-template <int ELEM, bool FAST, bool IDENT>
-__device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d, uint32_t v0, uint32_t n_values, uint32_t v_base,
+template <int ELEM, bool FAST, bool IDENT, class C>
+__device__ __forceinline__ void wp_unit(WholePageLdsT<C>& L, const pqd_page_desc& d, uint32_t v0, uint32_t n_values, uint32_t v_base,
                                         uint32_t w, uint32_t mask, u32x2 x[4]) {
   const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
   const uint32_t* runs = reinterpret_cast<const uint32_t*>(L.tab);
@@ -110,19 +173,19 @@ __device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d,
   const uint64_t bits = (uint64_t)L.flags[2 * wd] | ((uint64_t)L.flags[2 * wd + 1] << 32);
   uint32_t ri = L.wbase[wd] + (uint32_t)__builtin_popcountll(bits & ((2ull << sh) - 1ull)) - 1u;
   const uint32_t near = (uint32_t)(bits >> sh);  // bits 1..3: a run starts at value v0 + 1..3
-  uint32_t vw = v0 * w - WP_BIAS;
+  uint32_t vw = v0 * w - C::BIAS;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (k) ri += (near >> k) & 1u;
     const uint32_t e = runs[ri];
     if (FAST && !(e >> 31)) {
       if (ELEM == 4)
-        x[k].x = (runs + WP_VAL_RUNS)[ri];
+        x[k].x = (runs + C::VAL_RUNS)[ri];
       else
-        x[k] = reinterpret_cast<const u32x2*>(runs + WP_VAL_RUNS)[ri];
+        x[k] = reinterpret_cast<const u32x2*>(runs + C::VAL_RUNS)[ri];
     } else {
       const uint32_t bit = (e & 0x7FFFFFFFu) + vw;
-      const uint32_t i0 = (bit >> 5) & (WP_MAX_BYTES / 4 - 1u);  // (an RLE entry gives a meaningless but harmless index)
+      const uint32_t i0 = (bit >> 5) & (C::BYTES / 4 - 1u);  // (an RLE entry gives a meaningless but harmless index)
       uint32_t id = (e >> 31) ? funnel_shr(pgw[i0], pgw[i0 + 1], bit & 31u) & mask : e;
       if (IDENT) {
         x[k].x = id;  // readValueDictionaryId: the id is the value
@@ -143,16 +206,16 @@ __device__ __forceinline__ void wp_unit(WholePageLds& L, const pqd_page_desc& d,
 
 // Step 5 of dict_whole_page: per step two units of four values per thread, their lookups requested together (n_values:
 // the window's values; v_base: the page's values before it).
-template <int ELEM, bool FAST, bool IDENT>
-__device__ __forceinline__ void wp_values(WholePageLds& L, const pqd_page_desc& d, uint32_t n_values, uint32_t v_base, uint32_t w) {
+template <int ELEM, bool FAST, bool IDENT, class C>
+__device__ __forceinline__ void wp_values(WholePageLdsT<C>& L, const pqd_page_desc& d, uint32_t n_values, uint32_t v_base, uint32_t w) {
   const uint32_t mask = (1u << w) - 1u;
-  constexpr uint32_t STEP = WP_THREADS * 4u;
+  constexpr uint32_t STEP = (uint32_t)C::THREADS * 4u;
   for (uint32_t v0 = threadIdx.x * 4u; v0 < n_values; v0 += 2u * STEP) {
     u32x2 x[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const uint32_t vv = v0 + (uint32_t)u * STEP;
-      if (vv < n_values) wp_unit<ELEM, FAST, IDENT>(L, d, vv, n_values, v_base, w, mask, x[u]);
+      if (vv < n_values) wp_unit<ELEM, FAST, IDENT, C>(L, d, vv, n_values, v_base, w, mask, x[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -187,20 +250,32 @@ __device__ __forceinline__ void wp_values(WholePageLds& L, const pqd_page_desc& 
   }
 }
 
-// One dictionary page (d.data = [width][stream]) by the calling workgroup of WP_THREADS threads; L: its LDS, free for
-// this call.  The stream is taken a window of WP_MAX_BYTES at a time; a window ends in front of the first run that does
-// not fit into it.  false (for all threads): not decoded (what was written is written again by the caller's decoder).
-// IDENT: a page of dictionary ids read as ints (PQD_ENC_RLE with PQD_F_WIDTH_PREFIX, DictionaryValuesReader.readValueDictionaryId):
-// the same stream, the id itself is the value and no dictionary is looked at.
-template <int ELEM, bool IDENT = false>
-__device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result, WholePageLds& L) {
+// One page by the calling workgroup of WP_THREADS threads; L: its LDS, free for this call.  The stream is taken a window
+// of WP_MAX_BYTES at a time; a window ends in front of the first run that does not fit into it, or at its 32768th value.
+// false (for all threads): not decoded (what was written is written again by the caller's decoder).
+// IDENT: a page of plain hybrid values (levels, booleans, dictionary ids read as ints through
+// DictionaryValuesReader.readValueDictionaryId): the same stream, the id itself is the value and no dictionary is looked at.
+#ifdef WP_DEBUG
+#define WP_FAIL(code)                                                                          \
+  do {                                                                                         \
+    if (threadIdx.x == 0) printf("whole page: gives up at %d (page of %u values)\n", code, d.num_values); \
+    return false;                                                                              \
+  } while (0)
+#else
+#define WP_FAIL(code) return false
+#endif
+template <int ELEM, bool IDENT = false, class C = WpSmall>
+__device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result, WholePageLdsT<C>& L) {
   const uint32_t tid = threadIdx.x;
   const uint32_t n_page_values = d.num_values;
-  if (d.data_len < 2u || (!IDENT && d.dict == nullptr)) return false;
-  const uint32_t n_stream = d.data_len - 1u;
-  if (n_stream > WP_MAX_STREAM || n_page_values == 0u || n_page_values > WP_MAX_VALUES) return false;
-  // the width byte is requested here and looked at behind the first staging step: one trip to memory for both
-  const uint32_t w = ((const PQD_GLOBAL uint8_t*)d.data)[0];
+  if (!IDENT && d.dict == nullptr) WP_FAIL(1);
+  const WholeStream S = whole_stream_of(d, !IDENT);
+  if (!S.ok || n_page_values == 0u) WP_FAIL(2);
+  const uint32_t n_stream = S.n, w = S.w;
+  // (the small shape takes the pages of whole_page_candidate only; the long one anything the rules of either allow)
+  if (!whole_page_candidate(n_stream, n_page_values, w, IDENT ? 1u : d.dict_len, WP_MAX_STREAM) &&
+      !(C::SUPER && whole_page_long_candidate(n_stream, n_page_values, w, IDENT ? 1u : d.dict_len, WP_MAX_STREAM)))
+    WP_FAIL(3);
   if (tid == 0) {
     L.consumed = 0u;
     L.oob_at = ~0u;
@@ -215,11 +290,35 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
 #endif
   uint32_t base = 0;    // stream bytes before the window
   uint32_t v_base = 0;  // values before the window
+  uint32_t carry_n = 0, carry_val = 0;  // values left of an RLE run whose bytes lie before the window
   for (;;) {
-    const bool last = n_stream - base <= WP_MAX_BYTES;
-    const uint32_t N = last ? n_stream - base : WP_MAX_BYTES;
+    // ---- 0. what is left of an RLE run that the window before this one ended in: stored as it is
+    if (carry_n) {
+      const uint32_t take = carry_n < n_page_values - v_base ? carry_n : n_page_values - v_base;
+      u32x2 x = {carry_val, 0u};
+      if (!IDENT && carry_val < d.dict_len) {  // (beyond the dictionary: the run's first value has reported it)
+        if (ELEM == 4)
+          x.x = ((const PQD_GLOBAL uint32_t*)d.dict)[carry_val];
+        else
+          x = ((const PQD_GLOBAL u32x2_a4*)d.dict)[carry_val];
+      }
+      if (ELEM == 4) {
+        PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)d.out + v_base;
+        for (uint32_t i = tid; i < take; i += (uint32_t)C::THREADS) o[i] = x.x;
+      } else {
+        PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)d.out + v_base;
+        const u32x2_a4 e = {x.x, x.y};
+        for (uint32_t i = tid; i < take; i += (uint32_t)C::THREADS) o[i] = e;
+      }
+      v_base += take;
+      carry_n = 0;
+      if (v_base >= n_page_values) break;
+    }
+    const bool last = n_stream - base <= C::BYTES;
+    const uint32_t N = last ? n_stream - base : C::BYTES;
     const uint32_t n_values = n_page_values - v_base;  // values still wanted
-    const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.data + 1 + base;
+    const uint32_t n_window = n_values < C::VALUES ? n_values : C::VALUES;  // values this window delivers at most
+    const PQD_GLOBAL uint8_t* src = S.src + base;
     WP_STAMP();
     // ---- 1. the window -> LDS (zeros behind it).  Whole aligned dwords are read (none lies wholly outside the page) and
     // shifted into place: a piece of 16 stream bytes is five independent loads, whatever the page's address.
@@ -229,7 +328,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       const uint32_t off = (uint32_t)(a & 3u), sh = off * 8u;
       const uint32_t full = (off + N) >> 2;  // dwords wholly inside [aligned start, end of the window)
       const uint32_t tail = (off + N) & 3u;  // window bytes in dword `full`
-      for (uint32_t i = tid * 4u; i * 4u < N + 16u; i += WP_THREADS * 4u) {
+      for (uint32_t i = tid * 4u; i * 4u < N + 16u; i += (uint32_t)C::THREADS * 4u) {
         uint32_t x[5];
 #pragma unroll
         for (uint32_t k = 0; k < 5u; ++k) {
@@ -243,15 +342,15 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
         *reinterpret_cast<u32x4*>(L.pg + i * 4u) = v;
       }
     }
-    for (uint32_t i = tid; i < (n_values >> 5) + 4u; i += WP_THREADS) L.flags[i] = 0u;
-    if (tid < WP_BLOCKS) L.entry_of[tid] = 0xFFFFu;
+    for (uint32_t i = tid; i < (n_window >> 5) + 4u; i += (uint32_t)C::THREADS) L.flags[i] = 0u;
+    if (tid < (C::BYTES / WP_BLOCK)) L.entry_of[tid] = 0xFFFFu;
     if (tid == 0) {
       L.ok = 1u;
       L.rle_oob = 0u;
       L.n_eff = N;
+      L.cut_at = ~0u;
     }
     __syncthreads();
-    if (!whole_page_candidate(n_stream, n_page_values, w, IDENT ? 1u : d.dict_len, WP_MAX_STREAM)) return false;
     const uint32_t vb = (w + 7u) >> 3;
     const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
 
@@ -264,7 +363,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       const uint32_t n_blocks = (N + WP_BLOCK) / WP_BLOCK;  // the block that holds position N is included
       constexpr int SIDE = 4;  // blocks worked on side by side (their chains of lane exchanges are independent)
-      for (uint32_t b0 = wave * SIDE; b0 < n_blocks; b0 += SIDE * (WP_THREADS / 64)) {
+      for (uint32_t b0 = wave * SIDE; b0 < n_blocks; b0 += SIDE * ((uint32_t)C::THREADS / 64)) {
         uint32_t to[SIDE];
 #pragma unroll
         for (int q = 0; q < SIDE; ++q) {
@@ -295,50 +394,97 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     __syncthreads();
     WP_STAMP();
     // ---- 3. the chain, block by block; where it stops short of the window's end, the window ends there
-    if (tid == 0) {
-      uint32_t p = 0;
-      while (p < N) {
-        L.entry_of[p / WP_BLOCK] = (uint16_t)p;
-        const uint32_t q = L.tab[p];
-        if (q == WP_STOP) {  // the run that does not fit starts in this block: walk up to it
-          for (;;) {
-            const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
-            const WholeRun r = whole_run(lo, w, vb);
-            if (p + r.len > N) break;
-            p += r.len;
+    if constexpr (!C::SUPER) {
+      if (tid == 0) {
+        uint32_t p = 0;
+        while (p < N) {
+          L.entry_of[p / WP_BLOCK] = (uint16_t)p;
+          const uint32_t q = L.tab[p];
+          if (q == WP_STOP) {  // the run that does not fit starts in this block: walk up to it
+            for (;;) {
+              const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
+              const WholeRun r = whole_run(lo, w, vb);
+              if (p + r.len > N) break;
+              p += r.len;
+            }
+            L.n_eff = p;
+            p = N;
+            break;
           }
-          L.n_eff = p;
-          p = N;
-          break;
+          p = q;
         }
-        p = q;
+        if (p != N) L.ok = 0u;  // WP_COMPLEX met (a chain position beyond N cannot occur)
       }
-      if (p != N) L.ok = 0u;  // WP_COMPLEX met (a chain position beyond N cannot occur)
+    } else {
+      // 256 bytes at a hop: where a chain that enters at a byte leaves its four blocks (at most three more exits to
+      // follow; every thread takes its bytes side by side), one thread hops through the window, then a thread per 256
+      // bytes notes where the chain enters each of its four blocks.
+      for (uint32_t p = tid; p <= N; p += (uint32_t)C::THREADS) {
+        uint32_t t = L.tab[p];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (t < WP_STOP && t / WP_SUPER == p / WP_SUPER && t <= N) t = L.tab[t];
+        L.tab2[p] = (uint16_t)t;
+      }
+      if (tid <= C::BYTES / WP_SUPER) L.sentry[tid] = 0xFFFFu;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t p = 0;
+        while (p < N) {
+          L.sentry[p / WP_SUPER] = (uint16_t)p;
+          const uint32_t q = L.tab2[p];
+          if (q == WP_STOP) {  // the run that does not fit starts in these 256 bytes: walk up to it
+            for (;;) {
+              const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
+              const WholeRun r = whole_run(lo, w, vb);
+              if (p + r.len > N) break;
+              p += r.len;
+            }
+            L.n_eff = p;
+            p = N;
+            break;
+          }
+          p = q;
+        }
+        if (p != N) L.ok = 0u;  // WP_COMPLEX met
+      }
+      __syncthreads();
+      if (tid <= C::BYTES / WP_SUPER) {
+        uint32_t p = L.sentry[tid];
+        const uint32_t stop = (tid + 1u) * WP_SUPER;
+        while (p < stop && p < N) {  // (0xFFFF: the chain does not come through here)
+          L.entry_of[p / WP_BLOCK] = (uint16_t)p;
+          p = L.tab[p];  // (a mark ends the loop: it is above every position)
+        }
+      }
     }
     __syncthreads();
-    if (!L.ok) return false;
+    if (!L.ok) WP_FAIL(4);
     const uint32_t n_eff = L.n_eff;  // the window's bytes that are whole runs
-    if (n_eff == 0u) return false;   // a run longer than a window
+    if (n_eff == 0u) WP_FAIL(5);   // a run longer than a window
     WP_STAMP();
     // ---- 4. the runs of every block, numbered, with their first output value
     const uint32_t block_end = (tid + 1u) * WP_BLOCK;
     uint32_t my_runs = 0, my_vals = 0;
-    const uint32_t entry = tid < WP_BLOCKS ? L.entry_of[tid] : 0xFFFFu;
+    const uint32_t entry = tid < (C::BYTES / WP_BLOCK) ? L.entry_of[tid] : 0xFFFFu;
     if (entry != 0xFFFFu) {
       uint32_t p = entry;
       while (p < block_end && p < n_eff) {
         const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
         const WholeRun r = whole_run(lo, w, vb);
         ++my_runs;
-        my_vals += r.nvals < WP_MAX_VALUES ? r.nvals : WP_MAX_VALUES;
+        my_vals += r.nvals < C::VALUES ? r.nvals : C::VALUES;
         p += r.len;
       }
     }
     uint32_t total_runs, total_vals;
-    uint32_t run_i = wp_exclusive(my_runs, L.wave_totals, total_runs);
-    uint32_t val_i = wp_exclusive(my_vals, L.wave_totals, total_vals);
-    if (last && total_vals < n_values) return false;  // "Reading past RLE/BitPacking stream.": the other kernel reports it
-    const uint32_t nv = total_vals < n_values ? total_vals : n_values;  // values this window delivers
+    uint32_t run_i = wp_exclusive<C::THREADS>(my_runs, L.wave_totals, total_runs);
+    uint32_t val_i = wp_exclusive<C::THREADS>(my_vals, L.wave_totals, total_vals);  // (a run counts C::VALUES at most: sums stay small)
+    // "Reading past RLE/BitPacking stream.": the other kernel reports it
+    if (last && total_vals < n_window) WP_FAIL(6);
+    uint32_t nv = total_vals < n_window ? total_vals : n_window;  // values this window delivers
+    // more values in the window's runs than it delivers, and the page wants them: the window ends at its value nv
+    const bool cut = nv < n_values && nv < total_vals;
     uint32_t* runs = reinterpret_cast<uint32_t*>(L.tab);  // nobody reads the exits any more (barriers above)
     if (entry != 0xFFFFu) {
       const uint32_t vmask = vb >= 4u ? ~0u : (1u << (8u * vb)) - 1u;
@@ -347,38 +493,66 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
         const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
         const WholeRun r = whole_run(lo, w, vb);
         if (val_i < nv) {
-          // table entry: bit 31 set = bit-packed, then bits 0..30 = WP_BIAS + window bit of the run's first value - first
-          // value * w (value v of the run sits at entry + v * w - WP_BIAS); else the repeated value, its vb bytes as they
+          // table entry: bit 31 set = bit-packed, then bits 0..30 = C::BIAS + window bit of the run's first value - first
+          // value * w (value v of the run sits at entry + v * w - C::BIAS); else the repeated value, its vb bytes as they
           // are (the reference does not mask them to the width)
           const uint32_t q = p + r.nb;
           const uint32_t rep = funnel_shr(pgw[q >> 2], pgw[(q >> 2) + 1], (q & 3u) * 8u) & vmask;
-          runs[run_i] = r.packed ? (0x80000000u | (WP_BIAS + q * 8u - val_i * w)) : rep;
-          atomicOr(&L.flags[val_i >> 5], 1u << (val_i & 31u));
-          const uint32_t rv = r.nvals < WP_MAX_VALUES ? r.nvals : WP_MAX_VALUES;
-          if (val_i + rv >= n_values) L.consumed = base + p + r.len;  // the run that holds the page's last value: read whole (:95-99)
+          const bool crossing = cut && r.nvals > nv - val_i;  // the one run that reaches past the window's last value
+          if (crossing && r.packed) {
+            // the next window starts with it (one that starts this window is longer than a window takes: cut_nv 0)
+            L.cut_at = p;
+            L.cut_nv = val_i;
+            L.carry_n = 0u;
+          } else {
+            runs[run_i] = r.packed ? (0x80000000u | (C::BIAS + q * 8u - val_i * w)) : rep;
+            atomicOr(&L.flags[val_i >> 5], 1u << (val_i & 31u));
+            if (r.nvals >= n_values - val_i) L.consumed = base + p + r.len;  // the run that holds the page's last value: read whole (:95-99)
+            if (crossing) {  // an RLE run: the next window starts behind it, its remaining values in front
+              L.cut_at = p + r.len;
+              L.cut_nv = nv;
+              L.carry_n = r.nvals - (nv - val_i);
+              L.carry_val = rep;
+            }
+          }
+        } else if (cut && val_i == nv) {  // no run crosses: the next window starts with this one
+          L.cut_at = p;
+          L.cut_nv = nv;
+          L.carry_n = 0u;
         }
         ++run_i;
-        val_i += r.nvals < WP_MAX_VALUES ? r.nvals : WP_MAX_VALUES;
+        val_i += r.nvals < C::VALUES ? r.nvals : C::VALUES;
         p += r.len;
       }
+    }
+    __syncthreads();
+    uint32_t next_base = base + n_eff;
+    if (cut) {
+      if (L.cut_at == ~0u) WP_FAIL(7);  // (cannot happen: some run crosses)
+      nv = L.cut_nv;
+      next_base = base + L.cut_at;
+      carry_n = L.carry_n;
+      carry_val = L.carry_val;
+      if (nv == 0u) WP_FAIL(8);  // a bit-packed run of more values than a window takes
     }
     __syncthreads();
     WP_STAMP();
     // run starts before each 64-bit word of the bitmap
     uint32_t n_runs;  // runs that hold values of the window (the table's entries)
     {
-      const uint32_t words = (nv + 63u) >> 6;  // <= 512: two per thread
-      uint32_t c[2], sum = 0;
+      const uint32_t words = (nv + 63u) >> 6;
+      constexpr uint32_t PER = (C::VALUES / 64u + (uint32_t)C::THREADS - 1u) / (uint32_t)C::THREADS;  // words per thread
+      uint32_t c[PER], sum = 0;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint32_t wd = tid * 2u + k;
+      for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t wd = tid * PER + k;
         c[k] = wd < words ? (uint32_t)(__builtin_popcount(L.flags[2 * wd]) + __builtin_popcount(L.flags[2 * wd + 1])) : 0u;
         sum += c[k];
       }
-      uint32_t before = wp_exclusive(sum, L.wave_totals, n_runs);
+      uint32_t before = wp_exclusive<C::THREADS>(sum, L.wave_totals, n_runs);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        L.wbase[tid * 2u + k] = (uint16_t)before;
+      for (uint32_t k = 0; k < PER; ++k) {
+        L.wbase[tid * PER + k] = (uint16_t)before;
         before += c[k];
       }
     }
@@ -387,11 +561,11 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     // ---- 5. values.  A window of few runs: the dictionary entry of every RLE run is fetched once, by the threads side
     // by side, and kept behind the table (a lookup per VALUE costs the address path a cycle per lane: 20000 of them are
     // most of this routine's time).  An id beyond the dictionary among them leaves the window to the value-by-value form.
-    bool fast = n_runs <= WP_VAL_RUNS;
+    bool fast = n_runs <= C::VAL_RUNS;
     if (fast) {
       const uint32_t* runs_c = reinterpret_cast<const uint32_t*>(L.tab);
-      uint32_t* vals = reinterpret_cast<uint32_t*>(L.tab) + WP_VAL_RUNS;
-      for (uint32_t r = tid; r < n_runs; r += WP_THREADS) {
+      uint32_t* vals = reinterpret_cast<uint32_t*>(L.tab) + C::VAL_RUNS;
+      for (uint32_t r = tid; r < n_runs; r += (uint32_t)C::THREADS) {
         const uint32_t e = runs_c[r];
         if (e >> 31) continue;
         if (IDENT) {
@@ -409,19 +583,21 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     }
     WP_STAMP();
     if (fast)
-      wp_values<ELEM, true, IDENT>(L, d, nv, v_base, w);
+      wp_values<ELEM, true, IDENT, C>(L, d, nv, v_base, w);
     else
-      wp_values<ELEM, false, IDENT>(L, d, nv, v_base, w);
+      wp_values<ELEM, false, IDENT, C>(L, d, nv, v_base, w);
     __syncthreads();  // the window's LDS is done with
     WP_STAMP();
     v_base += nv;
     if (v_base >= n_page_values) break;
-    if (last) return false;  // (cannot happen: the last window delivers what is still wanted or has returned above)
-    base += n_eff;
+    if (last && !cut) WP_FAIL(9);  // (cannot happen: the last window delivers what is still wanted or has returned above)
+    base = next_base;
   }
+  __syncthreads();
   if (tid == 0) {
     const uint32_t oob = L.oob_at;
-    pqd_page_result r = {oob < n_page_values ? PQD_DICT_OOB : PQD_OK, oob < n_page_values ? oob : n_page_values, 1u + L.consumed, 0u};
+    const uint32_t used = S.consumed_all != ~0u ? S.consumed_all : S.prefix + L.consumed;
+    pqd_page_result r = {oob < n_page_values ? PQD_DICT_OOB : PQD_OK, oob < n_page_values ? oob : n_page_values, used, 0u};
     *result = r;
   }
 #ifdef PQD_PROF

@@ -874,3 +874,109 @@ def test_dictionary_run_heavy_pages_decoded_whole(gpu, orc, monkeypatch, elem):
             assert (guard == 0xA5).all(), (mode, i)
     for i, (a, b) in enumerate(zip(results["0"], results[None])):
         assert a[2] == b[2], (i, a[2], b[2])  # bytes consumed
+
+
+@pytest.mark.parametrize("kind", ["plain", "dict4", "dict8"])
+def test_long_run_heavy_pages_decoded_whole(gpu, orc, monkeypatch, kind):
+    """Pages of more than 32768 values (or 32 KiB of stream) made of many short runs are not planned either: the
+    left-over launch takes them window by window, a window ending at its 32768th value (inside an RLE run, whose
+    remaining values are then stored directly, or in front of a bit-packed run).  Plain hybrid pages with each kind of
+    prefix and dictionary pages; RLE runs of several windows' worth of values, a page that ends inside such a run,
+    bit-packed runs of more values than a window takes, ids beyond the dictionary in a later window and in the
+    carried part of a run, streams cut short.  PQD_WHOLE_MAX=0 switches the path off: both runs must agree with the
+    oracle and with each other in the bytes consumed."""
+    import parquet_java_amd as pq
+    rng = np.random.default_rng({"plain": 71, "dict4": 72, "dict8": 73}[kind])
+    pages, expect = [], []
+    elem = 8 if kind == "dict8" else 4
+    dt = np.int64 if elem == 8 else np.int32
+
+    def short_runs(n, w, mean):
+        lens = rng.geometric(1.0 / mean, n // max(mean // 2, 1) + 16)
+        vals = np.repeat(rng.integers(0, 1 << w, lens.size), lens)[:n]
+        assert vals.size == n
+        return vals.astype(np.uint32).view(np.int32)
+
+    def add_plain(w, vals, n, prefix, cut=0):
+        body = bytes(orc.rle_encode(w, vals))
+        if cut:
+            body = body[:len(body) - cut]
+        if prefix == "length":
+            data, flags, bw = len(body).to_bytes(4, "little") + body + b"\x99\x98", pq.F_LENGTH_PREFIX, w
+            ost, ovals, _ = orc.rle_decode(w, data, n, prefixed=True)
+        elif prefix == "width":
+            data, flags, bw = bytes([w]) + body, pq.F_WIDTH_PREFIX, 0
+            ost, ovals = orc.dict_decode_ids(data, n)
+        else:
+            data, flags, bw = body, 0, w
+            ost, ovals, _ = orc.rle_decode(w, body, n)
+        pages.append(gpu.Page(data, n, pq.ENC_RLE, 4, bit_width=bw, flags=flags))
+        expect.append((ost, ovals))
+
+    def add_dict(ids, n, d, cut=0):
+        data = np.asarray(orc.dict_encode_ids(ids, d.size if d.size > 1 << 12 else 1 << 12), np.uint8)
+        if cut:
+            data = data[:data.size - cut]
+        pages.append(gpu.Page(data, n, pq.ENC_RLE_DICTIONARY, elem, dictionary=d))
+        expect.append(orc.dict_decode(data, d, n))
+
+    if kind == "plain":
+        for i, (w, n, mean) in enumerate([(1, 40000, 30), (3, 32769, 12), (8, 100_000, 40), (12, 70_001, 9), (16, 1_000_000, 40), (24, 50_000, 20)]):
+            v = short_runs(n, w, mean)
+            add_plain(w, v, n, ("none", "width", "length")[i % 3])
+            add_plain(w, v, n + 20, ("width", "length", "none")[i % 3])     # reads past the encoded values
+            add_plain(w, v, n - 1234, ("length", "none", "width")[i % 3])  # the page ends inside the stream
+        w = 8
+        v = short_runs(300_000, w, 25)
+        v[50_000:250_000] = 77          # an RLE run of six windows' worth of values
+        for n in (300_000, 180_000, 50_000 + 32768, 50_009):
+            add_plain(w, v, n, "none")
+        v = short_runs(200_000, w, 25)
+        v[60_000:110_000] = rng.integers(0, 256, 50_000).astype(np.int32)  # bit-packed runs between the short ones
+        add_plain(w, v, 200_000, "width")
+        add_plain(w, v, 200_000, "none", cut=15_000)  # the stream ends short of the page
+        add_plain(w, v, 200_000, "length", cut=1)
+        # one bit-packed run of 40000 values behind a three-byte header, short runs around it
+        a, b = short_runs(50_000, w, 25), short_runs(50_000, w, 25)
+        mid = rng.integers(0, 256, 40_000).astype(np.int32)
+        hdr, h = [], ((40_000 // 8) << 1) | 1
+        while h >= 0x80:
+            hdr.append((h & 0x7F) | 0x80)
+            h >>= 7
+        hdr.append(h)
+        body = np.concatenate([orc.rle_encode(w, a), np.array(hdr, np.uint8), orc.pack(w, mid), orc.rle_encode(w, b)])
+        ost, ovals, _ = orc.rle_decode(w, bytes(body), 140_000)
+        pages.append(gpu.Page(bytes(body), 140_000, pq.ENC_RLE, 4, bit_width=w, flags=0))
+        expect.append((ost, ovals))
+    else:
+        d = rng.integers(-(1 << 31), 1 << 31, 50_000).astype(dt)
+        if elem == 8:
+            d = d * np.int64(0x100000001) + 5
+        for n, mean in ((40_000, 12), (250_000, 30), (1_000_000, 40)):
+            ids = short_runs(n, 15, mean)
+            add_dict(ids, n, d)
+            add_dict(ids, n - 4321, d)
+        ids = short_runs(200_000, 15, 20)
+        ids[70_000:160_000] = 41_000           # a long run
+        add_dict(ids, 200_000, d)
+        add_dict(ids, 120_000, d)
+        bad = ids.copy()
+        bad[70_000:160_000] = 60_000           # ... beyond the dictionary
+        add_dict(bad, 200_000, d)
+        bad = ids.copy()
+        bad[180_000:180_003] = (1, 65_000, 2)  # beyond the dictionary in a bit-packed group of a late window
+        add_dict(bad, 200_000, d)
+        add_dict(ids, 200_000, d, cut=9_000)   # the stream ends short of the page
+    results = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("PQD_WHOLE_MAX")
+        else:
+            monkeypatch.setenv("PQD_WHOLE_MAX", mode)
+        results[mode] = gpu.decode_pages(pages)
+        for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(results[mode], expect)):
+            assert st == ost and written == ovals.size, (mode, i, st, written, ost, ovals.size)
+            assert (out.view(dt)[:written] == ovals).all(), (mode, i)
+            assert (guard == 0xA5).all(), (mode, i)
+    for i, (a, b) in enumerate(zip(results["0"], results[None])):
+        assert a[2] == b[2], (i, a[2], b[2])  # bytes consumed

@@ -16,12 +16,14 @@ from oracle import oracle as orc  # noqa: E402
 def main():
     pq.init(0)
     dev = torch.device("cuda:0")
-    n_pages, n, elem = int(os.environ.get("WPP_PAGES", "5000")), 20000, 8
+    n_pages, n, elem = int(os.environ.get("WPP_PAGES", "5000")), int(os.environ.get("WPP_VALUES", "20000")), 8
     dic = np.random.default_rng(5).integers(-(1 << 62), 1 << 62, 65536).astype(np.int64)
     pages = []
     for i in range(n_pages):
         r = np.random.default_rng(1000 + i)
-        if os.environ.get("WPP_SHORT"):  # runs of 1..20 equal ids, unsorted
+        if os.environ.get("WPP_LONG"):  # runs of about 40 equal ids (WPP_VALUES=1000000: a long page)
+            x = np.repeat(r.integers(0, 65536, n // 30), r.geometric(1 / 40.0, n // 30))[:n].astype(np.int32)
+        elif os.environ.get("WPP_SHORT"):  # runs of 1..20 equal ids, unsorted
             x = np.repeat(r.integers(0, 65536, 2400), r.integers(1, 21, 2400))[:n].astype(np.int32)
         else:
             x = np.sort(r.integers(0, 65536, 600)).repeat(r.integers(1, 70, 600))[:n].astype(np.int32)
