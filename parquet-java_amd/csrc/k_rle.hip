@@ -306,7 +306,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
     static_assert(RLE_THREADS == WP_THREADS, "one workgroup shape for both parts");
     for (uint32_t page = blockIdx.x; page < n_pages; page += gridDim.x) {
       const pqd_page_desc d = descs[page];  // (requested together with the plan record: one trip to memory)
-      const uint32_t f = __builtin_amdgcn_readfirstlane(only_fallback[page].flags);
+      const uint32_t f = __builtin_amdgcn_readfirstlane(only_fallback[page].flags) & ~PLAN_F_LONG;  // (a long page given up: the mark beside PLAN_F_FALLBACK)
       if (f != PLAN_F_FALLBACK && f != PLAN_F_WHOLE) continue;
       __syncthreads();  // the previous page's LDS is done with
       if constexpr (HAS_DICT) {
@@ -341,13 +341,19 @@ __global__ __launch_bounds__(WpLong::THREADS) void k_whole_long_pages(const pqd_
                                                                       RlePagePlan* __restrict__ plans, uint32_t* __restrict__ cursor,
                                                                       uint32_t n_pages) {
   extern __shared__ u32x4 long_lds[];
-  const uint32_t page = blockIdx.x;
+  // plain values: two workgroups per page (each parses the page, each stores half of the values: a CU's stores are what
+  // the value step waits for, and a call of 128 pages leaves half of the CUs free)
+  constexpr uint32_t PARTS = HAS_DICT ? 1u : 2u;
+  const uint32_t page = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
   if (page >= n_pages) return;
-  if ((uint32_t)__builtin_amdgcn_readfirstlane((int)plans[page].flags) != PLAN_F_LONG) return;
+  const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&plans[page].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  // (the other part of the page may have finished already: both come to the same verdict, and write the same mark)
+  if (f != PLAN_F_LONG && !(PARTS > 1u && (f == (PLAN_F_LONG | PLAN_F_DONE) || f == (PLAN_F_LONG | PLAN_F_FALLBACK)))) return;
   const pqd_page_desc d = descs[page];
-  const bool done = dict_whole_page<ELEM, !HAS_DICT, WpLong>(d, results + page, *reinterpret_cast<WholePageLdsT<WpLong>*>(long_lds));
+  const bool done = dict_whole_page<ELEM, !HAS_DICT, WpLong>(d, results + page, *reinterpret_cast<WholePageLdsT<WpLong>*>(long_lds), part, PARTS);
   if (threadIdx.x == 0) {
-    plans[page].flags = done ? PLAN_F_DONE : PLAN_F_FALLBACK;
+    // PLAN_F_FALLBACK is what the left-over launch looks for; the long mark stays beside it for the page's other part
+    __hip_atomic_store(&plans[page].flags, PLAN_F_LONG | (done ? PLAN_F_DONE : PLAN_F_FALLBACK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!done) cursor[PLAN_CTR_FALLBACK] = 1u;
   }
 }
@@ -368,7 +374,7 @@ hipError_t launch_whole_long_pages(const pqd_page_desc* descs, pqd_page_result* 
     attr_set[which] = true;
   }
   RlePagePlan* pl = reinterpret_cast<RlePagePlan*>(plans);
-  const dim3 grid(n_pages), block(WpLong::THREADS);
+  const dim3 grid(has_dict ? n_pages : 2u * n_pages), block(WpLong::THREADS);
   if (!has_dict)
     hipLaunchKernelGGL((k_whole_long_pages<4, false>), grid, block, LDS, stream, descs, results, pl, cursor, n_pages);
   else if (elem == 4)

@@ -56,15 +56,18 @@ template <class C>
 struct alignas(16) WholePageLdsT {
   uint8_t pg[C::BYTES + 96];    // the stream, zeros behind it
   uint16_t tab[C::BYTES + 64];  // where a chain entering at each byte leaves its block; later the run table (as words)
-  uint16_t tab2[C::SUPER ? C::BYTES + 64 : 8];  // ... leaves its 256 bytes
+  uint16_t tab2[C::SUPER ? C::BYTES + 64 : 8];   // ... leaves its 256 bytes
+  uint16_t tab16[C::SUPER ? C::BYTES + 64 : 8];  // ... leaves its 16 bytes
   uint32_t flags[C::VALUES / 32 + 4];  // bit v: a run starts at value v
   uint16_t wbase[C::VALUES / 64 + 4];  // run starts before each 64-bit word of the bitmap
   uint16_t entry_of[C::BYTES / WP_BLOCK];  // where the chain enters each block
   uint16_t sentry[C::BYTES / WP_SUPER + 1];  // ... each 256 bytes
+  uint16_t entry16[C::SUPER ? C::BYTES / 16 : 8];  // ... each 16 bytes
   uint32_t wave_totals[C::THREADS / 64];
   uint32_t ok, consumed, oob_at, rle_oob, n_eff;
   uint32_t cut_at, cut_nv, carry_n, carry_val;  // a window that ends at its last value: where the next one starts
   static_assert(C::BYTES / WP_BLOCK <= (uint32_t)C::THREADS, "a thread per block");
+  static_assert(!C::SUPER || C::BYTES / 16 <= (uint32_t)C::THREADS, "a thread per 16 bytes");
   static_assert((C::BYTES / 2) * 4 <= sizeof(uint16_t) * (C::BYTES + 64), "the run table fits where the exits were");
   static_assert(C::VAL_RUNS * 12u <= sizeof(uint16_t) * (C::BYTES + 64) && (C::VAL_RUNS * 4u) % 8u == 0, "table and values fit where the exits were");
   static_assert((uint64_t)C::VALUES * 24u < C::BIAS && C::BIAS + C::BYTES * 8u < (1u << 31), "an entry holds the biased bit position");
@@ -250,6 +253,63 @@ __device__ __forceinline__ void wp_values(WholePageLdsT<C>& L, const pqd_page_de
   }
 }
 
+// Step 5 for plain values in the long shape, where most values lie in RLE runs: first every value of an RLE run (a unit
+// of four values reads its bitmap word and the runs' entries, nothing of the stream), then the bit-packed runs, a thread
+// per run (their first values are kept beside the run table, in tab2).  A value is stored once: units that touch a
+// bit-packed run leave its values out.
+template <class C>
+__device__ __forceinline__ void wp_values_split(WholePageLdsT<C>& L, const pqd_page_desc& d, uint32_t n_values, uint32_t v_base, uint32_t w,
+                                                uint32_t n_runs, uint32_t vt, uint32_t n_vt) {
+  const uint32_t* runs = reinterpret_cast<const uint32_t*>(L.tab);
+  const uint32_t* valof = reinterpret_cast<const uint32_t*>(L.tab2);
+  const uint32_t* pgw = reinterpret_cast<const uint32_t*>(L.pg);
+  PQD_GLOBAL uint32_t* out = (PQD_GLOBAL uint32_t*)d.out + v_base;
+  const uint32_t STEP = n_vt * 4u;
+  for (uint32_t v0 = vt * 4u; v0 < n_values; v0 += 2u * STEP) {
+    uint32_t e[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t vv = v0 + (uint32_t)u * STEP;
+      const uint32_t vc = vv < n_values ? vv : 0u;
+      const uint32_t wd = vc >> 6, sh = vc & 63u;  // the four values share a word of the bitmap
+      const uint64_t bits = (uint64_t)L.flags[2 * wd] | ((uint64_t)L.flags[2 * wd + 1] << 32);
+      uint32_t ri = L.wbase[wd] + (uint32_t)__builtin_popcountll(bits & ((2ull << sh) - 1ull)) - 1u;
+      const uint32_t near = (uint32_t)(bits >> sh);  // bits 1..3: a run starts at value vv + 1..3
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k) ri += (near >> k) & 1u;
+        e[u][k] = runs[ri];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t vv = v0 + (uint32_t)u * STEP;
+      if (vv >= n_values) continue;
+      const uint32_t any_packed = (e[u][0] | e[u][1] | e[u][2] | e[u][3]) >> 31;
+      if (!any_packed && vv + 4u <= n_values) {
+        const u32x4_a4 q = {e[u][0], e[u][1], e[u][2], e[u][3]};
+        PQD_STREAM_STORE((PQD_GLOBAL u32x4_a4*)(out + vv), q);
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+          if (vv + k < n_values && !(e[u][k] >> 31)) out[vv + k] = e[u][k];
+      }
+    }
+  }
+  const uint32_t mask = (1u << w) - 1u;
+  for (uint32_t r = vt; r < n_runs; r += n_vt) {
+    const uint32_t en = runs[r];
+    if (!(en >> 31)) continue;
+    const uint32_t a = valof[r], b = valof[r + 1u];
+    uint32_t bit = (en & 0x7FFFFFFFu) + a * w - C::BIAS;
+    for (uint32_t v = a; v < b; ++v) {
+      const uint32_t i0 = (bit >> 5) & (C::BYTES / 4 - 1u);
+      out[v] = funnel_shr(pgw[i0], pgw[i0 + 1], bit & 31u) & mask;
+      bit += w;
+    }
+  }
+}
+
 // One page by the calling workgroup of WP_THREADS threads; L: its LDS, free for this call.  The stream is taken a window
 // of WP_MAX_BYTES at a time; a window ends in front of the first run that does not fit into it, or at its 32768th value.
 // false (for all threads): not decoded (what was written is written again by the caller's decoder).
@@ -264,9 +324,12 @@ __device__ __forceinline__ void wp_values(WholePageLdsT<C>& L, const pqd_page_de
 #else
 #define WP_FAIL(code) return false
 #endif
+// part / parts: the workgroup is one of `parts` that decode the page together (plain values in the long shape only): each
+// parses every window and stores its share of the values; part 0 writes the result.
 template <int ELEM, bool IDENT = false, class C = WpSmall>
-__device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result, WholePageLdsT<C>& L) {
+__device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result, WholePageLdsT<C>& L, uint32_t part = 0, uint32_t parts = 1) {
   const uint32_t tid = threadIdx.x;
+  const uint32_t vt = part * (uint32_t)C::THREADS + tid, n_vt = parts * (uint32_t)C::THREADS;  // this thread among those of all parts
   const uint32_t n_page_values = d.num_values;
   if (!IDENT && d.dict == nullptr) WP_FAIL(1);
   const WholeStream S = whole_stream_of(d, !IDENT);
@@ -281,7 +344,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     L.oob_at = ~0u;
   }
 #ifdef PQD_PROF
-  uint64_t stamp[10];
+  uint64_t stamp[16];
   int n_stamp = 0;
 #define WP_STAMP() \
   if (base == 0u) stamp[n_stamp++] = __builtin_readcyclecounter()
@@ -304,11 +367,11 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       }
       if (ELEM == 4) {
         PQD_GLOBAL uint32_t* o = (PQD_GLOBAL uint32_t*)d.out + v_base;
-        for (uint32_t i = tid; i < take; i += (uint32_t)C::THREADS) o[i] = x.x;
+        for (uint32_t i = vt; i < take; i += n_vt) o[i] = x.x;
       } else {
         PQD_GLOBAL u32x2_a4* o = (PQD_GLOBAL u32x2_a4*)d.out + v_base;
         const u32x2_a4 e = {x.x, x.y};
-        for (uint32_t i = tid; i < take; i += (uint32_t)C::THREADS) o[i] = e;
+        for (uint32_t i = vt; i < take; i += n_vt) o[i] = e;
       }
       v_base += take;
       carry_n = 0;
@@ -344,6 +407,9 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     }
     for (uint32_t i = tid; i < (n_window >> 5) + 4u; i += (uint32_t)C::THREADS) L.flags[i] = 0u;
     if (tid < (C::BYTES / WP_BLOCK)) L.entry_of[tid] = 0xFFFFu;
+    if constexpr (C::SUPER) {
+      if (tid < C::BYTES / 16u) L.entry16[tid] = 0xFFFFu;
+    }
     if (tid == 0) {
       L.ok = 1u;
       L.rle_oob = 0u;
@@ -375,13 +441,26 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
           to[q] = r.complex ? WP_COMPLEX : (p + r.len > N ? (last ? WP_COMPLEX : WP_STOP) : lane + r.len);
           if (p == N) to[q] = WP_END;
         }
+        // (the long shape: the first three rounds stay inside the lane's 16 bytes, which at most eight runs leave; what they
+        // give is kept as well; two more rounds then cross the block's four quarters)
 #pragma unroll
         for (int round = 0; round < 5; ++round) {
           uint32_t further[SIDE];
 #pragma unroll
           for (int q = 0; q < SIDE; ++q) further[q] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((to[q] & 63u) << 2), (int)to[q]);
 #pragma unroll
-          for (int q = 0; q < SIDE; ++q) to[q] = to[q] < WP_BLOCK ? further[q] : to[q];
+          for (int q = 0; q < SIDE; ++q) {
+            const bool inside = C::SUPER && round < 3 ? to[q] < WP_BLOCK && (to[q] >> 4) == (lane >> 4) : to[q] < WP_BLOCK;
+            to[q] = inside ? further[q] : to[q];
+          }
+          if (C::SUPER && round == 2) {
+#pragma unroll
+            for (int q = 0; q < SIDE; ++q) {
+              const uint32_t p = (b0 + q) * WP_BLOCK + lane;
+              const uint32_t abs_to = to[q] >= WP_STOP ? (to[q] == WP_END ? N : to[q]) : (b0 + q) * WP_BLOCK + to[q];
+              if (p <= N) L.tab16[p] = (uint16_t)abs_to;
+            }
+          }
         }
 #pragma unroll
         for (int q = 0; q < SIDE; ++q) {
@@ -419,42 +498,69 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       // 256 bytes at a hop: where a chain that enters at a byte leaves its four blocks (at most three more exits to
       // follow; every thread takes its bytes side by side), one thread hops through the window, then a thread per 256
       // bytes notes where the chain enters each of its four blocks.
-      for (uint32_t p = tid; p <= N; p += (uint32_t)C::THREADS) {
-        uint32_t t = L.tab[p];
+      for (uint32_t p0 = tid; p0 <= N; p0 += 4u * (uint32_t)C::THREADS) {  // (four bytes side by side: their look-ups overlap)
+        uint32_t t[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (t < WP_STOP && t / WP_SUPER == p / WP_SUPER && t <= N) t = L.tab[t];
-        L.tab2[p] = (uint16_t)t;
+        for (uint32_t u = 0; u < 4u; ++u) {
+          const uint32_t p = p0 + u * (uint32_t)C::THREADS;
+          t[u] = L.tab[p <= N ? p : N];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+          for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t p = p0 + u * (uint32_t)C::THREADS;
+            const bool inside = t[u] < WP_STOP && t[u] / WP_SUPER == p / WP_SUPER && t[u] <= N;
+            const uint32_t further = L.tab[inside ? t[u] : 0u];
+            t[u] = inside ? further : t[u];
+          }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          const uint32_t p = p0 + u * (uint32_t)C::THREADS;
+          if (p <= N) L.tab2[p] = (uint16_t)t[u];
+        }
       }
       if (tid <= C::BYTES / WP_SUPER) L.sentry[tid] = 0xFFFFu;
       __syncthreads();
-      if (tid == 0) {
+      WP_STAMP();
+      if (tid < 64u) {  // the first wave, all lanes alike: positions and loop control stay in scalar registers
         uint32_t p = 0;
         while (p < N) {
           L.sentry[p / WP_SUPER] = (uint16_t)p;
-          const uint32_t q = L.tab2[p];
+          const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.tab2[p]);
           if (q == WP_STOP) {  // the run that does not fit starts in these 256 bytes: walk up to it
             for (;;) {
-              const uint32_t lo = funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u);
+              const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)funnel_shr(pgw[p >> 2], pgw[(p >> 2) + 1], (p & 3u) * 8u));
               const WholeRun r = whole_run(lo, w, vb);
               if (p + r.len > N) break;
               p += r.len;
             }
-            L.n_eff = p;
+            if (tid == 0) L.n_eff = p;
             p = N;
             break;
           }
           p = q;
         }
-        if (p != N) L.ok = 0u;  // WP_COMPLEX met
+        if (p != N && tid == 0) L.ok = 0u;  // WP_COMPLEX met
       }
       __syncthreads();
+      WP_STAMP();
       if (tid <= C::BYTES / WP_SUPER) {
         uint32_t p = L.sentry[tid];
         const uint32_t stop = (tid + 1u) * WP_SUPER;
         while (p < stop && p < N) {  // (0xFFFF: the chain does not come through here)
           L.entry_of[p / WP_BLOCK] = (uint16_t)p;
           p = L.tab[p];  // (a mark ends the loop: it is above every position)
+        }
+      }
+      __syncthreads();
+      if (tid < C::BYTES / WP_BLOCK) {  // ... and a thread per block where it enters each of the block's quarters
+        uint32_t p = L.entry_of[tid];
+        const uint32_t stop = (tid + 1u) * WP_BLOCK;
+        while (p < stop && p < N) {
+          L.entry16[p >> 4] = (uint16_t)p;
+          p = L.tab16[p];
         }
       }
     }
@@ -464,9 +570,15 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     if (n_eff == 0u) WP_FAIL(5);   // a run longer than a window
     WP_STAMP();
     // ---- 4. the runs of every block, numbered, with their first output value
-    const uint32_t block_end = (tid + 1u) * WP_BLOCK;
+    // (a thread per block; in the long shape a thread per quarter of a block)
+    const uint32_t block_end = (tid + 1u) * (C::SUPER ? 16u : WP_BLOCK);
     uint32_t my_runs = 0, my_vals = 0;
-    const uint32_t entry = tid < (C::BYTES / WP_BLOCK) ? L.entry_of[tid] : 0xFFFFu;
+    uint32_t entry = 0xFFFFu;
+    if constexpr (C::SUPER) {
+      if (tid < C::BYTES / 16u) entry = L.entry16[tid];
+    } else {
+      if (tid < (C::BYTES / WP_BLOCK)) entry = L.entry_of[tid];
+    }
     if (entry != 0xFFFFu) {
       uint32_t p = entry;
       while (p < block_end && p < n_eff) {
@@ -506,6 +618,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
             L.carry_n = 0u;
           } else {
             runs[run_i] = r.packed ? (0x80000000u | (C::BIAS + q * 8u - val_i * w)) : rep;
+            if constexpr (IDENT && C::SUPER) reinterpret_cast<uint32_t*>(L.tab2)[run_i] = val_i;  // (the 256-byte exits are done with)
             atomicOr(&L.flags[val_i >> 5], 1u << (val_i & 31u));
             if (r.nvals >= n_values - val_i) L.consumed = base + p + r.len;  // the run that holds the page's last value: read whole (:95-99)
             if (crossing) {  // an RLE run: the next window starts behind it, its remaining values in front
@@ -561,7 +674,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     // ---- 5. values.  A window of few runs: the dictionary entry of every RLE run is fetched once, by the threads side
     // by side, and kept behind the table (a lookup per VALUE costs the address path a cycle per lane: 20000 of them are
     // most of this routine's time).  An id beyond the dictionary among them leaves the window to the value-by-value form.
-    bool fast = n_runs <= C::VAL_RUNS;
+    bool fast = n_runs <= C::VAL_RUNS && !(IDENT && C::SUPER);
     if (fast) {
       const uint32_t* runs_c = reinterpret_cast<const uint32_t*>(L.tab);
       uint32_t* vals = reinterpret_cast<uint32_t*>(L.tab) + C::VAL_RUNS;
@@ -582,7 +695,11 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
       fast = L.rle_oob == 0u;
     }
     WP_STAMP();
-    if (fast)
+    if constexpr (IDENT && C::SUPER) {
+      if (tid == 0) reinterpret_cast<uint32_t*>(L.tab2)[n_runs] = nv;  // where the last run's values end
+      __syncthreads();
+      wp_values_split<C>(L, d, nv, v_base, w, n_runs, vt, n_vt);
+    } else if (fast)
       wp_values<ELEM, true, IDENT, C>(L, d, nv, v_base, w);
     else
       wp_values<ELEM, false, IDENT, C>(L, d, nv, v_base, w);
@@ -594,7 +711,7 @@ __device__ bool dict_whole_page(const pqd_page_desc& d, pqd_page_result* result,
     base = next_base;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && part == 0) {
     const uint32_t oob = L.oob_at;
     const uint32_t used = S.consumed_all != ~0u ? S.consumed_all : S.prefix + L.consumed;
     pqd_page_result r = {oob < n_page_values ? PQD_DICT_OOB : PQD_OK, oob < n_page_values ? oob : n_page_values, used, 0u};

@@ -35,6 +35,11 @@ def main():
         res = gpu.decode_pages([p for p, _ in pages])
         torch.cuda.synchronize()
         print(f"{n_p} pages, stream {len(pages[0][0].data)} bytes: {1e3 * (time.perf_counter() - t0):.2f} ms (with copies)")
+    if os.environ.get("LPP_PROF"):  # a library built with -DPQD_PROF leaves the cycles of the first window's steps in the first values
+        cyc = np.array([out.view(np.int32)[:9] for (_, _, _, out, _) in res]).astype(np.int64)
+        names = ["stage", "candidates + exits", "exits of 256 bytes", "hops", "entries", "runs", "word counts", "run values", "values"]
+        print("mean cycles per step of the first window:", {k: int(c) for k, c in zip(names, cyc.mean(0))})
+        return
     for (st, written, used, out, guard), (p, v) in zip(res, pages):
         assert st == 0 and written == nvals and (out.view(np.int32)[:written] == v).all()
     print("values fine")
