@@ -95,6 +95,17 @@ struct LwLds {
 #define LW_PROF_PASS
 #endif
 
+// (development build -DLW_WATCHDOG: a loop that runs four million times says so and ends)
+#ifdef LW_WATCHDOG
+#define LW_DOG(var, where)                                                                        \
+  if (++(var) > (1u << 22)) {                                                                     \
+    if ((threadIdx.x & 63u) == 0) printf("k_lz watchdog: loop %d, block %u wave %u\n", where, blockIdx.x, threadIdx.x >> 6); \
+    break;                                                                                        \
+  }
+#else
+#define LW_DOG(var, where) (void)(var);
+#endif
+
 struct LwSeq {
   bool ok;
   uint32_t next, lit_len, lit_pos, mlen, offset;
@@ -197,8 +208,8 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
   __syncthreads();
   LW_STAMP(0)
   if (wave == 0) {
-    // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more: neither of
-    // the two continues at the other)
+    // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither
+    // of the two continues at the other; the one exception is dealt with below)
     const uint32_t seg = w0 + lane * 32u;
     for (int pl = 31; pl >= 1; pl -= 2) {
       LwSeq s[2];
@@ -214,13 +225,16 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) at_j[u] = L.u.p.place[lane * 33u + j[u]];
+      u32x2 e[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const bool inside = s[u].ok && s[u].next < seg + 32u;
-        u32x2 e;
-        e.x = !s[u].ok ? LW_FAIL : inside ? at_j[u].x : s[u].next;
-        e.y = !s[u].ok ? 0u : s[u].lit_len + s[u].mlen + (((s[u].lit_len ? 1u : 0u) + (s[u].mlen ? 1u : 0u)) << 24) + (inside ? at_j[u].y : 0u);
-        L.u.p.place[lane * 33u + (uint32_t)(pl - u)] = e;
+        // (LZ4's last sequence may be its token alone: the lower place of the pair then continues at the upper one, whose
+        // entry is not in the table yet)
+        if (u == 1 && j[1] == (uint32_t)pl) at_j[1] = e[0];
+        e[u].x = !s[u].ok ? LW_FAIL : inside ? at_j[u].x : s[u].next;
+        e[u].y = !s[u].ok ? 0u : s[u].lit_len + s[u].mlen + (((s[u].lit_len ? 1u : 0u) + (s[u].mlen ? 1u : 0u)) << 24) + (inside ? at_j[u].y : 0u);
+        L.u.p.place[lane * 33u + (uint32_t)(pl - u)] = e[u];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -231,7 +245,9 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     {
       uint32_t at = ip, elems = 0;
       uint64_t made = op;
+      uint32_t dog1 = 0;
       while (at < w0 + LW_WIN && at < in_end && made <= cap) {
+        LW_DOG(dog1, 1)
         const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
         const u32x2 e = L.u.p.place[k * 33u + pl];
         const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
@@ -254,7 +270,9 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     if (entry != LW_NONE) {
       uint32_t q = entry, i = first_elem;
       uint64_t o = first_out;
+      uint32_t dog2 = 0;
       while (q < seg + 32u && q < in_end) {
+        LW_DOG(dog2, 2)
         const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
         if (!s.ok || s.lit_len >= LW_HUGE || s.mlen >= LW_HUGE || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
           stop = true;
@@ -315,14 +333,18 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       cell[lane] = 0;
       cell[lane + 64u] = 0;
       __builtin_amdgcn_wave_barrier();
+      uint32_t dog3 = 0;
       for (;;) {
+        LW_DOG(dog3, 3)
         const uint32_t i = e_lo + lane;
         const bool in_front = i < n_elems && L.e_out[i] <= tb;
         const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
         e_lo += (uint32_t)__builtin_popcountll(m);
         if (m != ~0ull) break;
       }
+      uint32_t dog4 = 0;
       for (uint32_t b = e_lo;; b += 64u) {
+        LW_DOG(dog4, 4)
         const uint32_t i = b + lane;
         const uint32_t eo = i < n_elems ? L.e_out[i] : 0xFFFFFFFFu;
         const bool inside = eo < te;
@@ -387,7 +409,9 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     __syncthreads();
     LW_STAMP(5)
     // every byte follows its pointer until it arrives at a byte that has its value
+    uint32_t dog5 = 0;
     while (L.flag[round % 3u]) {
+      LW_DOG(dog5, 5)
       ++round;
       if (tid == 0) L.flag[(round + 1u) % 3u] = 0;  // (the flag of the round after this one: last read two rounds ago)
       const bool was_open = open;
@@ -501,7 +525,9 @@ __device__ __forceinline__ void lw_copy_match(PQD_GLOBAL uint8_t* dst, uint32_t 
 // LZ4's length bytes (each adds its value; the first one below 255 is the last), 64 at a time.  false: the stream ends
 // inside them (ip then lies at its end, as a byte-by-byte reader leaves it).
 __device__ __forceinline__ bool lw_length_bytes(const PQD_GLOBAL uint8_t* src, uint32_t& ip, uint32_t in_end, uint64_t& sum, uint32_t lane) {
+  uint32_t dog6 = 0;
   for (;;) {
+    LW_DOG(dog6, 6)
     const bool inside = ip + lane < in_end;
     const uint32_t b = inside ? (uint32_t)src[ip + lane] : 0u;
     const uint64_t ends = __builtin_amdgcn_ballot_w64(!inside || b != 255u);
@@ -625,7 +651,9 @@ __global__ __launch_bounds__(LW_WAVES * 64) void k_lz_pages(const pqd_decompress
   uint64_t prof_t = __builtin_readcyclecounter();
 #endif
   if (status == PQD_OK) {
+    uint32_t dog7 = 0;
     while (ip < in_end) {
+      LW_DOG(dog7, 7)
       if (!lw_window<CODEC>(L, src, dst, ip, op, in_end, cap, tid LW_PROF_PASS)) continue;
       if (ip >= in_end) break;
       // one sequence by the first wave; the others learn where it ended

@@ -525,6 +525,35 @@ def test_gpu_decompresses_library_streams_and_pages(orc, codec_name):
 
 
 @pytest.mark.gpu
+def test_gpu_lz4_stream_that_ends_with_a_lone_token(orc):
+    """The last sequence of an LZ4 block has no match; with no literals either it is one byte long, the only sequence of
+    fewer than two bytes in either format.  Streams that end that way behind a match, at every place of a 32-byte
+    segment, and the one-byte stream of an empty page; a batch of ordinary pages runs in front, so that the tables in
+    LDS hold another page's entries."""
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(77)
+    filler = []
+    for v in VECTORS:
+        if v["codec"] == "LZ4_RAW":
+            filler.append((base64.b64decode(v["compressed"]), v["size"]))
+    items = [(b"\x00", 0)]
+    for n_lit in range(1, 40):
+        lits = bytes(rng.integers(97, 123, n_lit, dtype=np.uint8))
+        head = bytes([0xF0, n_lit - 15]) if n_lit >= 15 else bytes([n_lit << 4])
+        items.append((head + lits + b"\x01\x00" + b"\x00", n_lit + 4))  # literals, a match of 4 from 1 back, a token alone
+    for stream, size in items:
+        assert orc.decompress("LZ4_RAW", stream, size)[0] == 0
+    for misalign in (0, 3):
+        run_batch(pq, gh, torch, CODEC_NUM["LZ4_RAW"], filler, misalign)
+        results = run_batch(pq, gh, torch, CODEC_NUM["LZ4_RAW"], items, misalign)
+        check_batch(orc, "LZ4_RAW", items, results)
+        assert all(st == 0 for st, _, _ in results)
+
+
+@pytest.mark.gpu
 def test_gpu_snappy_far_copies_in_front_of_literals(orc):
     import torch
     import parquet_java_amd as pq
