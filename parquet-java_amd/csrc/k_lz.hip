@@ -31,6 +31,8 @@
 // Measured and dropped: an element per lane copying its bytes in order, with an LDS ring of the last 32 KiB of output
 // (fewer instructions when matches reach far back, three times slower when most matches read what the 64 elements
 // of their own batch write, as in columns of small numbers and repetitive text).
+#include <cstdlib>
+
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 
@@ -57,9 +59,10 @@ constexpr uint32_t LW_HAS = 0x80000000u;  // a tile cell that holds its byte
 #ifndef LW_UNROLL
 #define LW_UNROLL 4u
 #endif
-#ifndef LW_WAVES
-#define LW_WAVES 4u  // waves per page
-#endif
+// Waves per page: four when thousands of pages are in flight (the parse is one wave's, and seven pages a CU keep its
+// SIMDs busy), eight or sixteen when a call has few pages (the tiles' bytes are shared out among more lanes; measured
+// on 1 MiB pages of text: 256 pages 32 / 39 / 45 GB/s with 4 / 8 / 16 waves, 1792 pages 99 / 66 / 45).
+constexpr uint32_t LW_FEW_PAGES = 384, LW_SOME_PAGES = 768;
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // window byte q in LDS (no padding between the lanes' segments: the instructions of an address with padding cost more
@@ -186,9 +189,9 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
 
 // One window: the sequences from stream position ip on, as far as the window (or the chain of well-formed
 // sequences) goes; their output is written.  ip / op move behind them.  Returns true when the chain stopped in
-// front of a sequence that the caller has to take by itself.  All LW_WAVES waves of the workgroup call it: the parse
+// front of a sequence that the caller has to take by itself.  All WAVES waves of the workgroup call it: the parse
 // is the first wave's, the tiles' bytes are shared out among all of them.
-template <int CODEC>
+template <int CODEC, uint32_t WAVES>
 __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op,
                                           uint32_t in_end, uint32_t cap, uint32_t tid LW_PROF_ARGS) {
   const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -196,7 +199,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
   const uint32_t staged = in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
   // ---- the window -> LDS
   __syncthreads();
-  for (uint32_t t = tid * 16u; t < staged - w0; t += LW_WAVES * 1024u) {
+  for (uint32_t t = tid * 16u; t < staged - w0; t += WAVES * 1024u) {
     if (t + 16u <= staged - w0) {
       u32x4 v;
       __builtin_memcpy(&v, (const uint8_t*)(src + w0 + t), 16);
@@ -369,7 +372,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     // a word per byte of the tile: LW_HAS | the byte, or the tile position of the byte it repeats
     const uint32_t n_steps = (te - tb + 63u) >> 6;
     bool open = false;
-    for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += LW_WAVES * LW_UNROLL) {
+    for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += WAVES * LW_UNROLL) {
       uint32_t eo[LW_UNROLL], es[LW_UNROLL], word[LW_UNROLL];
 #pragma unroll
       for (uint32_t u = 0; u < LW_UNROLL; ++u) {
@@ -417,7 +420,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       const bool was_open = open;
       open = false;
       if (__builtin_amdgcn_ballot_w64(was_open)) {
-        for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += LW_WAVES * LW_UNROLL) {
+        for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += WAVES * LW_UNROLL) {
           uint32_t mine_[LW_UNROLL], other[LW_UNROLL];
 #pragma unroll
           for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
@@ -441,7 +444,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     {
       PQD_GLOBAL uint8_t* gbase = dst + tb - a;  // 16-byte aligned
       const uint32_t stop_at = a + (te - tb);
-      for (uint32_t t = tid * 16u; t < stop_at; t += LW_WAVES * 1024u) {
+      for (uint32_t t = tid * 16u; t < stop_at; t += WAVES * 1024u) {
         // the bytes of tile positions t - a .. t - a + 15
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -605,8 +608,8 @@ __device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL
   return true;
 }
 
-template <int CODEC>
-__global__ __launch_bounds__(LW_WAVES * 64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
+template <int CODEC, uint32_t WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
                                                             pqd_page_result* __restrict__ results, uint32_t n_pages) {
   __shared__ LwLds L;
   const uint32_t page = blockIdx.x;
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(LW_WAVES * 64) void k_lz_pages(const pqd_decompress
     uint32_t dog7 = 0;
     while (ip < in_end) {
       LW_DOG(dog7, 7)
-      if (!lw_window<CODEC>(L, src, dst, ip, op, in_end, cap, tid LW_PROF_PASS)) continue;
+      if (!lw_window<CODEC, WAVES>(L, src, dst, ip, op, in_end, cap, tid LW_PROF_PASS)) continue;
       if (ip >= in_end) break;
       // one sequence by the first wave; the others learn where it ended
       if (tid < 64u) {
@@ -720,11 +723,25 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
   }
 }
 
-static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
+template <uint32_t WAVES>
+static void launch_lz_waves(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
   if (codec == PQD_CODEC_SNAPPY)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY>), dim3(n_pages), dim3(LW_WAVES * 64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
   else if (codec == PQD_CODEC_LZ4_RAW)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW>), dim3(n_pages), dim3(LW_WAVES * 64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+}
+
+static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
+  // PQD_LZ_WAVES = 4, 8 or 16 fixes the waves per page (testing)
+  const char* env = getenv("PQD_LZ_WAVES");
+  const int forced = env ? atoi(env) : 0;
+  const uint32_t waves = forced == 4 || forced == 8 || forced == 16 ? (uint32_t)forced : n_pages <= LW_FEW_PAGES ? 16u : n_pages <= LW_SOME_PAGES ? 8u : 4u;
+  if (waves == 16u)
+    launch_lz_waves<16u>(descs, results, n_pages, codec, stream);
+  else if (waves == 8u)
+    launch_lz_waves<8u>(descs, results, n_pages, codec, stream);
+  else
+    launch_lz_waves<4u>(descs, results, n_pages, codec, stream);
 }
 
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,

@@ -554,6 +554,21 @@ def test_gpu_lz4_stream_that_ends_with_a_lone_token(orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+def test_gpu_lz_pages_with_four_and_eight_waves(orc, monkeypatch, codec_name, waves):
+    """The Snappy / LZ4 kernel runs sixteen waves per page in calls of few pages (every test here), eight and four in
+    larger ones: the same streams with the number of waves fixed."""
+    monkeypatch.setenv("PQD_LZ_WAVES", waves)
+    test_gpu_decompresses_library_streams_and_pages(orc, codec_name)
+    test_gpu_damaged_streams(orc, codec_name)
+    if codec_name == "LZ4_RAW":
+        test_gpu_lz4_stream_that_ends_with_a_lone_token(orc)
+    else:
+        test_gpu_snappy_far_copies_in_front_of_literals(orc)
+
+
+@pytest.mark.gpu
 def test_gpu_snappy_far_copies_in_front_of_literals(orc):
     import torch
     import parquet_java_amd as pq
