@@ -26,7 +26,7 @@ namespace pqd {
 
 constexpr uint32_t PB_WIN = 4096;
 constexpr uint32_t PB_NONE = 0xFFFFFFFFu;
-constexpr uint32_t PB_FAIL = 0x80000000u;
+constexpr uint32_t PB_FAIL = 0x00800000u, PB_REL = 0x007FFFFFu;  // a table entry: values on the way << 24 | PB_FAIL | exit - w0 (saturated)
 
 // byte q of the window in LDS: four bytes of padding behind every 64-byte segment, so that the lanes' segments
 // start in different banks
@@ -35,13 +35,12 @@ __device__ __forceinline__ uint32_t pb_at(uint32_t q) { return q + ((q >> 6) << 
 struct PbLds {
   uint8_t win[PB_WIN + 64 + 4 * 66];
   union {
-    uint32_t exits[64 * 65];  // steps 1 and 2
+    uint32_t exits[64 * 65];  // steps 1 and 2: per place, where the chain from it leaves the segment and how many values it passes
     struct {                  // steps 3 and 4
       uint32_t offs[PB_WIN / 4 + 4];
       __attribute__((aligned(16))) uint8_t out[PB_WIN + 48];
     } t;
   } u;
-  uint8_t counts[64 * 68];
   uint64_t starts[64];   // per segment: places where a value starts
   uint64_t lengths[64];  // per segment: bytes of length fields
   uint32_t before[64];   // values that start in front of the segment (from the page's first)
@@ -58,9 +57,9 @@ __device__ __forceinline__ uint32_t pb_length_at(const uint8_t* win, uint32_t q)
 // Can a value that starts at page position `pos` be read (its length is `len`)?  Then `next` = where the value
 // behind it starts.
 __device__ __forceinline__ bool pb_value_at(uint32_t pos, uint32_t len, uint32_t data_len, uint32_t& next) {
-  const uint64_t end = (uint64_t)pos + 4u + len;
-  next = (uint32_t)end;
-  return (uint64_t)pos + 4u <= data_len && (int32_t)len >= 0 && end <= data_len;
+  // (pos and data_len are below 2^31, and so is a length that is not negative: the sums fit 32 bits)
+  next = pos + 4u + len;
+  return (int32_t)len >= 0 && pos + 4u <= data_len && next <= data_len;
 }
 
 __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_desc* __restrict__ descs,
@@ -85,6 +84,12 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
   const uint32_t data_len = b.data_len, n = b.num_values;
   const uint32_t cap = bytes ? (b.bytes_capacity > 0x7fffffffu ? 0x7fffffffu : b.bytes_capacity) : 0x7fffffffu;
 
+#ifdef PB_PROF  // development: cycles of each step, summed over the page, printed by page 0
+  uint64_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = __builtin_readcyclecounter();
+#define PB_T(k) { const uint64_t now_ = __builtin_readcyclecounter(); pt[k] += now_ - pt_last; pt_last = now_; }
+#else
+#define PB_T(k)
+#endif
   uint32_t w0 = 0;       // page position of the window
   uint32_t cur = 0;      // where the next value starts
   uint32_t idx = 0;      // values delivered
@@ -131,25 +136,41 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
       }
     }
     __syncthreads();  // (one wave: an order for the LDS accesses)
-    // ---- 1. the segment's places, last to first
+    PB_T(0)
+    // ---- 1. the segment's places, last to first, four at a time (a value is its four length bytes at least: none of
+    // the four continues at another).  The lane's 64 bytes and the four behind them sit in registers: a place's
+    // length field is a funnel shift, and the only trips to LDS are the look-ups of the places the values end at.
     const uint32_t seg = w0 + lane * 64u;
-    for (int p = 63; p >= 0; --p) {
-      uint32_t next;
-      const bool ok = pb_value_at(seg + (uint32_t)p, pb_length_at(L.win, lane * 64u + (uint32_t)p), data_len, next);
-      uint32_t ex = PB_FAIL, c = 0;
-      if (ok) {
-        if (next >= seg + 64u) {
-          ex = next;
-          c = 1;
-        } else {
-          ex = L.u.exits[lane * 65u + (next - seg)];
-          c = L.counts[lane * 68u + (next - seg)] + 1u;
+    {
+      uint32_t sb[17];
+      const uint32_t* own = reinterpret_cast<const uint32_t*>(L.win + lane * 68u);  // (pb_at: 64 bytes, four of padding)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sb[k] = own[k];
+      sb[16] = own[17];
+#pragma unroll
+      for (int g = 15; g >= 0; --g) {
+        uint32_t next[4], j[4], e_j[4];
+        bool ok[4], inside[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = 4 * g + 3 - u;
+          const uint32_t len = (p & 3) ? funnel_shr(sb[p >> 2], sb[(p >> 2) + 1], (uint32_t)(p & 3) * 8u) : sb[p >> 2];
+          ok[u] = pb_value_at(seg + (uint32_t)p, len, data_len, next[u]);
+          inside[u] = ok[u] && next[u] < seg + 64u;
+          j[u] = inside[u] ? next[u] - seg : 63u;  // (the look-up is made in any case)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e_j[u] = L.u.exits[lane * 65u + j[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = 4 * g + 3 - u;
+          const uint32_t rel = next[u] - w0 < PB_REL ? next[u] - w0 : PB_REL;  // (at or beyond the window's end: the chain ends there)
+          L.u.exits[lane * 65u + (uint32_t)p] = !ok[u] ? PB_FAIL : (inside[u] ? e_j[u] : rel) + (1u << 24);
         }
       }
-      L.u.exits[lane * 65u + (uint32_t)p] = ex;
-      L.counts[lane * 68u + (uint32_t)p] = (uint8_t)c;
     }
     __syncthreads();
+    PB_T(1)
     // ---- 2. the chain through the window
     const uint32_t idx0 = idx;
     uint32_t entry = PB_NONE, first_index = 0;
@@ -157,17 +178,18 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
       uint32_t at = cur, total = idx0;
       while (at < w0 + PB_WIN) {
         const uint32_t k = (at - w0) >> 6, p = (at - w0) & 63u;
-        const uint32_t ex = pb_uni(L.u.exits[k * 65u + p]), c = pb_uni(L.counts[k * 68u + p]);
+        const uint32_t e = pb_uni(L.u.exits[k * 65u + p]);
         if (lane == k) {
           entry = at;
           first_index = total;
         }
-        total += c;
-        if ((ex & PB_FAIL) || total >= n) break;
-        at = ex;
+        total += e >> 24;
+        if ((e & PB_FAIL) || total >= n) break;
+        at = w0 + (e & PB_REL);
       }
     }
     __syncthreads();  // the tables are done with: their room becomes the tiles
+    PB_T(2)
     // ---- 3. the values of this lane's segment
     uint64_t starts = 0;
     uint32_t mine = 0, end = 0;
@@ -226,23 +248,34 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
     L.lengths[lane] = lens;
     L.before[lane] = idx0 + inc - mine;
     __syncthreads();
+    PB_T(3)
     // ---- 4. the value bytes, squeezed together
     // (when the window ends inside a length field, the bytes of that field behind the window are not in `limit`)
     const uint32_t out_end = limit - 4u * idx + (limit == w0 + PB_WIN ? spill_next : 0u);
     if (bytes) {
       const uint32_t a = (uint32_t)((uintptr_t)(bytes + run_out) & 15u);
       const uint64_t upto = (2ull << lane) - 1ull;
-      for (uint32_t t = 0; t < 64u; ++t) {
-        const uint32_t q = w0 + t * 64u + lane;
-        if (w0 + t * 64u >= limit) break;
-        const uint64_t s = L.starts[t], l = L.lengths[t];
-        const uint32_t bf = L.before[t];
-        if (q < limit && !((l >> lane) & 1ull)) {
-          const uint32_t dst = q - 4u * (bf + (uint32_t)__builtin_popcountll(s & upto));
-          L.u.t.out[a + (dst - run_out)] = L.win[pb_at(t * 64u + lane)];
+      for (uint32_t t0 = 0; t0 < 64u && w0 + t0 * 64u < limit; t0 += 4u) {  // four segments side by side
+        uint64_t s[4], l[4];
+        uint32_t bf[4], byte[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          s[u] = L.starts[t0 + u];
+          l[u] = L.lengths[t0 + u];
+          bf[u] = L.before[t0 + u];
+          byte[u] = L.win[pb_at((t0 + u) * 64u + lane)];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+          const uint32_t q = w0 + (t0 + u) * 64u + lane;
+          if (q < limit && !((l[u] >> lane) & 1ull)) {
+            const uint32_t dst = q - 4u * (bf[u] + (uint32_t)__builtin_popcountll(s[u] & upto));
+            L.u.t.out[a + (dst - run_out)] = (uint8_t)byte[u];
+          }
         }
       }
       __syncthreads();
+      PB_T(4)
       PQD_GLOBAL uint8_t* gbase = bytes + run_out - a;  // 16-byte aligned
       const uint32_t stop_at = a + (out_end - run_out);
       for (uint32_t t = lane * 16u; t < stop_at; t += 1024u) {
@@ -259,7 +292,13 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
     spill = spill_next;
     w0 += PB_WIN;
     __syncthreads();
+    PB_T(5)
   }
+#ifdef PB_PROF
+  if (page == 0 && lane == 0)
+    printf("k_plain_byte_array, page 0, cycles/1000: stage %llu, places %llu, chain %llu, values %llu, squeeze %llu, stores %llu\n", pt[0] / 1000,
+           pt[1] / 1000, pt[2] / 1000, pt[3] / 1000, pt[4] / 1000, pt[5] / 1000);
+#endif
   if (lane == 0) {
     offsets[idx] = (int32_t)run_out;
     pqd_page_result r = {status, idx, cur, run_out};
