@@ -262,3 +262,78 @@ def test_gpu_run_heavy_dictionary_pages_damaged(orc, elem, monkeypatch):
             assert (guard == 0xA5).all(), (mode, i)
     for i, (a, b) in enumerate(zip(results["0"], results[None])):
         assert a[2] == b[2] or a[0] != 0, (i, a[2], b[2])  # bytes consumed (where the page decoded)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plain", "dict4", "dict8"])
+def test_gpu_long_run_heavy_pages_damaged(orc, kind, monkeypatch):
+    """Long pages of many short runs of random shape (the pages k_whole_long_pages takes: 33 000 to 600 000 values, widths
+    1..24, runs of random mean length, long RLE runs and bit-packed stretches mixed in), as written and with a few bytes
+    damaged, cut short, followed by junk, or asked for more or fewer values than they hold: status, count and values are
+    the oracle's, and the consumed bytes are those of the planned path (PQD_WHOLE_MAX=0)."""
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng({"plain": 8100, "dict4": 8104, "dict8": 8108}[kind])
+    elem = 8 if kind == "dict8" else 4
+    dt = np.int64 if elem == 8 else np.int32
+    pages, expect = [], []
+    for k in range(36):
+        w = int(rng.integers(1, 25))
+        n = int(rng.choice([33_000, 70_000, 150_000, 262_144, 262_145, 600_000]))
+        mean = int(rng.choice([9, 15, 40, 63]))
+        lens = rng.geometric(1.0 / mean, 2 * n // mean + 64)
+        vals = np.repeat(rng.integers(0, 1 << w, lens.size), lens)[:n].astype(np.int64)
+        if vals.size < n:
+            vals = np.concatenate([vals, np.full(n - vals.size, vals[-1])])
+        if k % 3 == 0:  # an RLE run of several windows' worth of values
+            a = int(rng.integers(0, n // 2))
+            vals[a:a + int(rng.integers(40_000, 400_000))] = int(rng.integers(0, 1 << w))
+        if k % 4 == 1:  # a stretch without repeats
+            a = int(rng.integers(0, n - 3000))
+            vals[a:a + 3000] = rng.integers(0, 1 << w, 3000)
+        body = orc.rle_encode(w, vals.astype(np.uint32).view(np.int32))
+        damage = k % 5
+        if damage == 1:
+            body = body.copy()
+            hits = rng.integers(0, body.size, int(rng.integers(1, 4)))
+            body[hits] = rng.integers(0, 256, hits.size)
+        elif damage == 2:
+            body = body[:int(rng.integers(body.size // 2, body.size + 1))]
+        elif damage == 3:
+            body = np.concatenate([body, rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)])
+        want = n if k % 6 else int(n * rng.uniform(0.4, 1.2))
+        if kind == "plain":
+            flavour = k % 3
+            if flavour == 0:
+                data, flags, bw = body, 0, w
+                ost, ovals, _ = orc.rle_decode(w, bytes(body), want)
+            elif flavour == 1:
+                data, flags, bw = np.concatenate([np.array([w], np.uint8), body]), pq.F_WIDTH_PREFIX, 0
+                ost, ovals = orc.dict_decode_ids(data, want)
+            else:
+                data = np.concatenate([np.frombuffer(int(body.size).to_bytes(4, "little"), np.uint8), body, np.array([0x99, 0x98], np.uint8)])
+                flags, bw = pq.F_LENGTH_PREFIX, w
+                ost, ovals, _ = orc.rle_decode(w, bytes(data), want, prefixed=True)
+            pages.append(gh.Page(data, want, pq.ENC_RLE, 4, bit_width=bw, flags=flags))
+            expect.append((ost, ovals))
+        else:
+            reach = 1 << w
+            n_dict = int(min(reach, rng.integers(1, 70000))) if rng.random() < 0.7 else int(reach // 2 + 1)
+            dic = rng.integers(-(1 << 31), 1 << 31, n_dict).astype(dt)
+            data = np.concatenate([np.array([w], np.uint8), body])
+            pages.append(gh.Page(data, want, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            expect.append(orc.dict_decode(data, dic, want))
+    results = {}
+    for mode in ("0", None):
+        if mode is None:
+            monkeypatch.delenv("PQD_WHOLE_MAX")
+        else:
+            monkeypatch.setenv("PQD_WHOLE_MAX", mode)
+        results[mode] = gh.decode_pages(pages)
+        for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(results[mode], expect)):
+            assert st == ost and written == ovals.size, (mode, i, st, ost, written, ovals.size)
+            assert (out.view(dt)[:written] == ovals).all(), (mode, i)
+            assert (guard == 0xA5).all(), (mode, i)
+    for i, (a, b) in enumerate(zip(results["0"], results[None])):
+        assert a[2] == b[2] or a[0] != 0, (i, a[2], b[2])  # bytes consumed (where the page decoded)
