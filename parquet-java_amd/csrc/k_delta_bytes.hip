@@ -348,13 +348,15 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     {
       PQD_GLOBAL uint8_t* gbase = dst - a;  // 16-byte aligned
       const uint32_t end = a + out_bytes;
-      for (uint32_t t = lane * 16u; t < end; t += 1024u) {
-        if (t >= a && t + 16u <= end) {
-          *(PQD_GLOBAL u32x4*)(gbase + t) = *reinterpret_cast<const u32x4*>(out_tile + t);
-        } else {
-          for (uint32_t k = 0; k < 16u; ++k)
-            if (t + k >= a && t + k < end) gbase[t + k] = out_tile[t + k];
-        }
+      for (uint32_t t = lane * 16u; t < end; t += 1024u)
+        if (t >= a && t + 16u <= end) *(PQD_GLOBAL u32x4*)(gbase + t) = *reinterpret_cast<const u32x4*>(out_tile + t);
+      // the two pieces that are not wholly the batch's: a lane per byte (lanes 0..15 the first piece, 16..31 the last)
+      {
+        const uint32_t first_piece = a >> 4, last_piece = end >> 4;  // (a < 16: first_piece is 0)
+        const bool head = (a & 15u) != 0u, tail = (end & 15u) != 0u && !(head && last_piece == first_piece);
+        const uint32_t k = lane < 16u ? first_piece * 16u + lane : last_piece * 16u + (lane - 16u);
+        const bool wanted = lane < 16u ? head : lane < 32u && tail;
+        if (wanted && k >= a && k < end) gbase[k] = out_tile[k];
       }
     }
     last_len = shuffle_u32((uint32_t)len, m - 1);
