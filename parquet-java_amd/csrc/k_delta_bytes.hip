@@ -308,21 +308,25 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     // the values in order, a lane per byte column.  Every lane reads and writes for every value: a read outside the
     // value's suffix is not used, a write behind the value's end lands where a later value (or nobody) writes.
     // (prefix and suffix lengths are below 2^16 here, tile positions below 2^14: two values per register to hand round)
-    const uint32_t ps = p | (s << 16), so_o = ((first + (uint32_t)so - p) & (LZ_STAGE - 1u)) | (o << 16);
+    // (bit 12 of the second: the value is longer than 64 bytes.  Lanes behind the batch stand for an empty value at the
+    // last value's place: taking them rewrites that value's bytes, which changes nothing)
+    const uint32_t o_last = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)(m - 1u));
+    const uint32_t ps = mine ? p | (s << 16) : 0u;
+    const uint32_t so_o = mine ? ((first + (uint32_t)so - p) & (LZ_STAGE - 1u)) | (p + s > 64u ? 0x1000u : 0u) | (o << 16) : o_last << 16;
     for (uint32_t k0 = 0; k0 < m; k0 += 4u) {
       uint32_t pk[4], sk[4], to[4], base[4], r0[4], r1[4];
-      bool wide = false;
+      uint32_t wide_bits = 0;
 #pragma unroll
       for (uint32_t u = 0; u < 4u; ++u) {
-        const uint32_t k = k0 + u < m ? k0 + u : m - 1u;  // (behind the batch: its last value once more, which changes nothing)
-        const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)k), b_ = (uint32_t)__builtin_amdgcn_readlane((int)so_o, (int)k);
+        const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(k0 + u)), b_ = (uint32_t)__builtin_amdgcn_readlane((int)so_o, (int)(k0 + u));
         pk[u] = a_ & 0xFFFFu;
         sk[u] = a_ >> 16;
-        base[u] = b_ & 0xFFFFu;  // where the byte of column 0 would lie in the stage, if the suffix began there
+        base[u] = b_ & 0xFFFu;  // where the byte of column 0 would lie in the stage, if the suffix began there
         to[u] = b_ >> 16;
-        wide = wide || pk[u] + sk[u] > 64u;
+        wide_bits |= b_;
         r0[u] = in_stage[(base[u] + lane) & (LZ_STAGE - 1u)];
       }
+      const bool wide = (wide_bits & 0x1000u) != 0u;
       if (wide) {
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) r1[u] = in_stage[(base[u] + lane + 64u) & (LZ_STAGE - 1u)];
