@@ -157,6 +157,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_delta_length_bytes(const pqd_del
 // ---- DELTA_BYTE_ARRAY ---------------------------------------------------------------------------------
 
 constexpr uint32_t DB_IN = LZ_CHUNK;  // suffix bytes of a batch at most: they lie in the two chunks of the suffix stream that LDS holds
+#ifndef DB_STEP
+#define DB_STEP 4u  // values per step of the column loop
+#endif
 constexpr uint32_t DB_OUT = 8192;   // assembled bytes of a batch
 constexpr uint32_t DB_COLUMNS = 128; // byte columns held in the lanes' registers: longer values go one at a time
 
@@ -313,11 +316,11 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
     const uint32_t o_last = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)(m - 1u));
     const uint32_t ps = mine ? p | (s << 16) : 0u;
     const uint32_t so_o = mine ? ((first + (uint32_t)so - p) & (LZ_STAGE - 1u)) | (p + s > 64u ? 0x1000u : 0u) | (o << 16) : o_last << 16;
-    for (uint32_t k0 = 0; k0 < m; k0 += 4u) {
-      uint32_t pk[4], sk[4], to[4], base[4], r0[4], r1[4];
+    for (uint32_t k0 = 0; k0 < m; k0 += DB_STEP) {
+      uint32_t pk[DB_STEP], sk[DB_STEP], to[DB_STEP], base[DB_STEP], r0[DB_STEP], r1[DB_STEP];
       uint32_t wide_bits = 0;
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
+      for (uint32_t u = 0; u < DB_STEP; ++u) {
         const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(k0 + u)), b_ = (uint32_t)__builtin_amdgcn_readlane((int)so_o, (int)(k0 + u));
         pk[u] = a_ & 0xFFFFu;
         sk[u] = a_ >> 16;
@@ -329,9 +332,9 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
       const bool wide = (wide_bits & 0x1000u) != 0u;
       if (wide) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) r1[u] = in_stage[(base[u] + lane + 64u) & (LZ_STAGE - 1u)];
+        for (uint32_t u = 0; u < DB_STEP; ++u) r1[u] = in_stage[(base[u] + lane + 64u) & (LZ_STAGE - 1u)];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
+        for (uint32_t u = 0; u < DB_STEP; ++u) {
           c0 = lane - pk[u] < sk[u] ? r0[u] : c0;
           c1 = lane + 64u - pk[u] < sk[u] ? r1[u] : c1;
           out_tile[to[u] + lane] = (uint8_t)c0;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(64) void k_delta_byte_array(const pqd_delta_bytes_d
         }
       } else {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
+        for (uint32_t u = 0; u < DB_STEP; ++u) {
           c0 = lane - pk[u] < sk[u] ? r0[u] : c0;
           out_tile[to[u] + lane] = (uint8_t)c0;
         }
