@@ -317,7 +317,7 @@ struct BackWords {
     return w >= 0 && w < n_words ? words[w] : 0u;
   }
   __device__ __forceinline__ void start(int32_t bitpos) {
-    base = (bitpos >> 5) - 63;
+    base = (bitpos >> 5) - 62;  // (the word above the one a field starts in is read as well: it is a lane of `cur` too)
     cur = load(base);
     nxt = load(base - 60);
   }
@@ -329,13 +329,15 @@ struct BackWords {
       nxt = load(base - 60);
     }
   }
-  // the k <= 32 bits from bit `lo` up
-  __device__ __forceinline__ uint32_t field(int32_t lo, uint32_t k) const {
+  // the 32 bits from bit `lo` up
+  __device__ __forceinline__ uint32_t raw(int32_t lo) const {
     const uint32_t w = (uint32_t)((lo >> 5) - base);
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)w);
-    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(w < 63u ? w + 1u : 63u));
-    return (uint32_t)((((uint64_t)b << 32) | a) >> ((uint32_t)lo & 31u)) & (uint32_t)((1ull << k) - 1ull);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(w + 1u));
+    return (uint32_t)((((uint64_t)b << 32) | a) >> ((uint32_t)lo & 31u));
   }
+  // the k <= 31 bits from bit `lo` up
+  __device__ __forceinline__ uint32_t field(int32_t lo, uint32_t k) const { return raw(lo) & ((1u << k) - 1u); }
 };
 
 // one table of the sequences section (kind 0: literal lengths, 1: offsets, 2: match lengths); returns bytes used or ~0u
@@ -797,7 +799,8 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           uint32_t rep0 = uni(sh.rep[0]), rep1 = uni(sh.rep[1]), rep2 = uni(sh.rep[2]);
           u32x2 eo = sh.of[so], em = sh.ml[sm], el = sh.ll[sl];
 #ifdef ZS_PROF
-          uint64_t zp[3] = {0, 0, 0}, zt = __builtin_readcyclecounter();
+          uint64_t zp[3] = {0, 0, 0}, zt = __builtin_readcyclecounter(), zfar_cycles = 0;
+          uint32_t zfar[4] = {0, 0, 0, 0};
 #define ZS_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); zp[k] += now_ - zt; zt = now_; }
 #else
 #define ZS_STAMP(k)
@@ -807,18 +810,21 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             // where the six fields lie follows from the three entries alone
             const uint32_t oy = uni(eo.y), my = uni(em.y), ly = uni(el.y), m_base = uni(em.x), l_base = uni(el.x);
             const uint32_t ob = oy & 0xFFu, mb = my & 0xFFu, lb = ly & 0xFFu;
-            const int32_t at_o = bit - (int32_t)ob, at_m = at_o - (int32_t)mb, at_l = at_m - (int32_t)lb;
+            const int32_t at_o = bit - (int32_t)ob, at_l = at_o - (int32_t)(mb + lb);
             const uint32_t ov = (1u << ob) + bb.field(at_o, ob);
-            const uint32_t ml = m_base + bb.field(at_m, mb);
-            const uint32_t ll = l_base + bb.field(at_l, lb);
+            // the bits behind the two length baselines lie side by side (32 at most): one look at the stream for both
+            const uint32_t both = bb.raw(at_l);
+            const uint32_t ml = m_base + ((both >> lb) & ((1u << mb) - 1u));
+            const uint32_t ll = l_base + (both & ((1u << lb) - 1u));
             bit = at_l;
             if (i + 1 < n_seq) {
+              // ... and so do the bits of the three next states (26 at most)
               const uint32_t nl = (ly >> 8) & 0xFFu, nm = (my >> 8) & 0xFFu, no = (oy >> 8) & 0xFFu;
-              const int32_t at_sl = at_l - (int32_t)nl, at_sm = at_sl - (int32_t)nm, at_so = at_sm - (int32_t)no;
-              sl = (ly >> 16) + bb.field(at_sl, nl);
-              sm = (my >> 16) + bb.field(at_sm, nm);
-              so = (oy >> 16) + bb.field(at_so, no);
-              bit = at_so;
+              bit = at_l - (int32_t)(nl + nm + no);
+              const uint32_t three = bb.raw(bit);
+              sl = (ly >> 16) + ((three >> (nm + no)) & ((1u << nl) - 1u));
+              sm = (my >> 16) + ((three >> no) & ((1u << nm) - 1u));
+              so = (oy >> 16) + (three & ((1u << no) - 1u));
               // (the next sequence's entries are on their way while this one's bytes are moved)
               eo = sh.of[so];
               em = sh.ml[sm];
@@ -828,23 +834,14 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               status = PQD_DECODE;
               break;
             }
-            uint32_t offset;
-            if (ov > 3u) {
-              offset = (uint32_t)(ov - 3u);
-              rep2 = rep1;
-              rep1 = rep0;
-              rep0 = offset;
-            } else {
-              const uint32_t idx = ov - 1u + (ll == 0 ? 1u : 0u);
-              if (idx == 0) {
-                offset = rep0;
-              } else {
-                offset = idx == 3 ? rep0 - 1u : idx == 1 ? rep1 : rep2;
-                if (idx > 1) rep2 = rep1;
-                rep1 = rep0;
-                rep0 = offset;
-              }
-            }
+            // the offset: a new one (the three kept ones move down), or one of the kept ones (RFC 8878 3.1.1.5), without branches
+            const bool fresh = ov > 3u;
+            const uint32_t idx = ov - 1u + (ll == 0 ? 1u : 0u);  // (meaningful when not fresh: 0..3)
+            const uint32_t kept = idx == 0u ? rep0 : idx == 1u ? rep1 : idx == 2u ? rep2 : rep0 - 1u;
+            const uint32_t offset = fresh ? ov - 3u : kept;
+            rep2 = fresh || idx > 1u ? rep1 : rep2;
+            rep1 = fresh || idx > 0u ? rep0 : rep1;
+            rep0 = offset;
             if (ll > lit_left || ll > cap - op) {
               status = PQD_DECODE;
               break;
@@ -857,12 +854,22 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               status = PQD_DECODE;
               break;
             }
+#ifdef ZS_PROF
+            zfar[0] += offset > ZS_RING ? 1u : 0u;
+            zfar[1] += offset > 4u * ZS_RING ? 1u : 0u;
+            zfar[2] += offset < 64u ? 1u : 0u;
+            zfar[3] += ll == 0u ? 1u : 0u;
+            const uint64_t zm0 = __builtin_readcyclecounter();
+#endif
             out.match(op, offset, ml);
+#ifdef ZS_PROF
+            if (offset > ZS_RING) zfar_cycles += __builtin_readcyclecounter() - zm0;
+#endif
             op += ml;
             ZS_STAMP(2)
           }
 #ifdef ZS_PROF
-          if (page == 0 && lane == 0) printf("block: %u sequences, cycles per sequence: decode %llu, literals %llu, match %llu\n", n_seq, zp[0] / n_seq, zp[1] / n_seq, zp[2] / n_seq);
+          if (page == 0 && lane == 0) printf("block: %u sequences, cycles per sequence: decode %llu, literals %llu, match %llu; offsets beyond the ring %u (%llu cycles each), beyond four rings %u, below 64: %u, without literals %u\n", n_seq, zp[0] / n_seq, zp[1] / n_seq, zp[2] / n_seq, zfar[0], zfar[0] ? zfar_cycles / zfar[0] : 0ull, zfar[1], zfar[2], zfar[3]);
 #endif
           __syncthreads();
           sh.rep[0] = rep0;

@@ -113,8 +113,10 @@ struct OutRing {
   }
   // `from_memory`: the caller knows that the ring no longer holds the source bytes (offset of 64 or more)
   __device__ __forceinline__ void match(uint32_t op, uint32_t offset, uint32_t len, bool from_memory = false) {
-    uint32_t lm = lane;  // lane mod offset for offsets below 64: six conditional subtractions
-    if (offset < 64u) {
+    // lane mod offset, for a match that repeats the `offset` < 64 bytes in front of it (a shorter one reads below its
+    // own first byte anyway): six conditional subtractions
+    uint32_t lm = lane;
+    if (offset < 64u && len > offset) {
 #pragma unroll
       for (int k = 5; k >= 0; --k) {
         const uint32_t t = offset << k;
