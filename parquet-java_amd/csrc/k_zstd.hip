@@ -14,6 +14,8 @@
 // or before the page's end); they are then staged through LDS like the input.  Tables live in LDS for the
 // whole frame (repeat modes and treeless literals reuse them).
 // Latency-bound like the other codecs (a serial chain per page); throughput is the number of pages in flight.
+#include <cstdlib>
+
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 #include "pqd_lz_common.hpp"
@@ -104,7 +106,7 @@ __device__ __forceinline__ bool zfse_build(uint32_t* tab, const int16_t* norm, u
     }
   }
   if (pos != 0) return false;
-  __syncthreads();
+  lz_sync();
   for (uint32_t u = 0; u < size; ++u) {
     const uint32_t s = tab[u] & 0xFFu;
     const uint32_t ns = next[s];  // (the lanes of the wave run in step: all have read before any writes)
@@ -112,7 +114,7 @@ __device__ __forceinline__ bool zfse_build(uint32_t* tab, const int16_t* norm, u
     const uint32_t nb = log - zhighbit(ns);
     tab[u] = s | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16);
   }
-  __syncthreads();
+  lz_sync();
   return true;
 }
 
@@ -178,7 +180,7 @@ __device__ __forceinline__ bool zhuf_build(ZShared& sh, uint32_t n_given) {
   const uint32_t rest = (1u << max_bits) - total;
   if (rest & (rest - 1u)) return false;
   sh.weights[n_given] = (uint8_t)(zhighbit(rest) + 1u);
-  __syncthreads();
+  lz_sync();
   const uint32_t n = n_given + 1;
   uint32_t start[13], cnt[13];
   for (int r = 0; r < 13; ++r) start[r] = cnt[r] = 0;
@@ -206,7 +208,7 @@ __device__ __forceinline__ bool zhuf_build(ZShared& sh, uint32_t n_given) {
   }
   sh.huf_bits = max_bits;
   sh.huf_valid = 1;
-  __syncthreads();
+  lz_sync();
   return true;
 }
 
@@ -229,7 +231,7 @@ __device__ __forceinline__ uint32_t zhuf_tree(ZShared& sh, InStage& in, uint32_t
     uint32_t n_sym, log;
     const uint32_t tb = zfse_norm(in, p0 + 1, hb, sh.norm, n_sym, 255, log, 6);
     if (tb == ~0u) return ~0u;
-    __syncthreads();
+    lz_sync();
     if (!zfse_build(sh.wtab, sh.norm, sh.next, n_sym, log)) return ~0u;
     const uint32_t sp = p0 + 1 + tb, sn = hb - tb;
     if (sn == 0) return ~0u;
@@ -263,7 +265,7 @@ __device__ __forceinline__ uint32_t zhuf_tree(ZShared& sh, InStage& in, uint32_t
       s2 = (e2 >> 16) + zback_small(in, sp, sn, bit, nb);
     }
   }
-  __syncthreads();
+  lz_sync();
   if (!zhuf_build(sh, n_w)) return ~0u;
   return used;
 }
@@ -350,7 +352,7 @@ __device__ __forceinline__ uint32_t zseq_table(ZShared& sh, InStage& in, u32x2* 
     if (n < 1) return ~0u;
     const uint32_t s = zbyte(in, p0);
     if (s > max_sym) return ~0u;
-    __syncthreads();
+    lz_sync();
     sh.tab32[0] = s;
     log = 0;
     used = 1;
@@ -364,17 +366,17 @@ __device__ __forceinline__ uint32_t zseq_table(ZShared& sh, InStage& in, u32x2* 
       used = zfse_norm(in, p0, n, sh.norm, n_sym, max_sym, log, max_log);
       if (used == ~0u) return ~0u;
     }
-    __syncthreads();
+    lz_sync();
     if (!zfse_build(sh.tab32, sh.norm, sh.next, n_sym, log)) return ~0u;
   }
-  __syncthreads();
+  lz_sync();
   // (symbols are max_sym at most: the description cannot hold more)
   for (uint32_t u = in.lane; u < (1u << log); u += 64u) {
     const uint32_t e = sh.tab32[u], sym = e & 0xFFu;
     const uint32_t code = kind == 1u ? sym << 24 : kind == 0u ? sh.ll_code[sym] : sh.ml_code[sym];
     tab[u] = u32x2{code & 0xFFFFFFu, (e & 0xFFFFFF00u) | (code >> 24)};
   }
-  __syncthreads();
+  lz_sync();
   tlog = log;
   have = 1;
   return used;
@@ -437,24 +439,201 @@ __device__ __forceinline__ uint64_t zxxh64(const PQD_GLOBAL uint8_t* p, uint32_t
   return h;
 }
 
-__global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __restrict__ descs,
-                                                   pqd_page_result* __restrict__ results, uint32_t n_pages) {
-  __shared__ ZShared sh;
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZS_RING];
-  __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
-  __shared__ __attribute__((aligned(16))) uint8_t s_lits[LZ_STAGE];
-  const uint32_t page = blockIdx.x;
-  if (page >= n_pages) return;
-  const pqd_decompress_desc d = descs[page];
-  if (d.codec != (uint32_t)PQD_CODEC_ZSTD) return;  // another kernel's page
-  const uint32_t lane = threadIdx.x;
-  if (d.src_len > 0x7fffffffu) {
-    if (lane == 0) {
-      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
-      results[page] = r;
-    }
-    return;
+// ---- where a page's bytes are moved.  The page's serial part (headers, tables, the sequences' bit stream) hands over
+// "copy n literals", "repeat ml bytes from offset back", ... : in a call of many pages the same wave carries them out at
+// once (ZDirect); in a call of few pages a second wave of the workgroup does (ZPush -> queue in LDS -> zstd_consume), so
+// that moving the bytes of a sequence runs beside the decode of the next ones.
+struct ZExec {
+  OutRing out;
+  InStage lits;
+  const PQD_GLOBAL uint8_t* in_base;  // the input from its aligned base (raw blocks)
+  uint32_t op, lit_pos, lt, rle_byte, lane;
+
+  __device__ __forceinline__ void init(uint8_t* ring, uint8_t* lit_stage, const pqd_decompress_desc& d, uint32_t lane_) {
+    out = OutRing{ring, (PQD_GLOBAL uint8_t*)d.dst, lane_, ZS_RING - 1u};
+    in_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
+    lane = lane_;
+    lits.lane = lane_;
+    lits.lds = lit_stage;
+    op = lit_pos = lt = rle_byte = 0;
   }
+  // the literals of the block that begins: from memory (lt 0: the input; 2 / 3: decoded by the other side, which has
+  // waited for its stores) or one byte repeated (lt 1)
+  __device__ __forceinline__ void set_literals(uint32_t lt_, const PQD_GLOBAL uint8_t* base, uint32_t pos, uint32_t end, uint32_t rle) {
+    lt = lt_;
+    rle_byte = rle;
+    lit_pos = pos;
+    if (lt_ != 1u) {
+      if (lt_ >= 2u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      lits.base = base;
+      lits.end = end;
+      lits.cur = 0;
+      lits.win_at = 0x80000000u;
+      lits.win0 = lits.win1 = 0;
+      lits.start(pos / LZ_CHUNK);
+    }
+  }
+  __device__ __forceinline__ void literals(uint32_t n) {
+    if (lt == 1u) {
+      for (uint32_t i = lane; i < n; i += 64u) {
+        out.ring[(op + i) & out.ring_mask] = (uint8_t)rle_byte;
+        out.dst[op + i] = (uint8_t)rle_byte;
+      }
+    } else {
+      for (uint32_t done = 0; done < n;) {
+        const uint32_t nn = n - done < 1900u ? n - done : 1900u;
+        lits.reach(lit_pos + done);
+        out.literal(lits, lit_pos + done, op + done, nn, 1900u);
+        done += nn;
+      }
+    }
+    lit_pos += n;
+    op += n;
+  }
+  __device__ __forceinline__ void match(uint32_t offset, uint32_t ml) {
+    out.match(op, offset, ml);
+    op += ml;
+  }
+  __device__ __forceinline__ void raw(uint32_t p, uint32_t size) {  // a raw block: input position p
+    const PQD_GLOBAL uint8_t* src = in_base + p;
+#pragma unroll 4
+    for (uint32_t i = lane; i < size; i += 64u) {
+      const uint8_t v = src[i];
+      out.ring[(op + i) & out.ring_mask] = v;
+      out.dst[op + i] = v;
+    }
+    op += size;
+  }
+  __device__ __forceinline__ void rle_block(uint32_t byte, uint32_t size) {
+    for (uint32_t i = lane; i < size; i += 64u) {
+      out.ring[(op + i) & out.ring_mask] = (uint8_t)byte;
+      out.dst[op + i] = (uint8_t)byte;
+    }
+    op += size;
+  }
+  // the frame's content checksum: the low 32 bits of XXH64 of what the frame produced
+  __device__ __forceinline__ bool frame_end(uint32_t frame_start, uint32_t want) {
+    return uni((uint32_t)zxxh64(out.dst + frame_start, op - frame_start, lane)) == want;
+  }
+};
+
+struct ZDirect {
+  static constexpr bool PIPELINED = false;
+  ZExec& x;
+  __device__ __forceinline__ void set_literals(uint32_t lt, const PQD_GLOBAL uint8_t* base, uint32_t pos, uint32_t end, uint32_t rle) {
+    x.set_literals(lt, base, pos, end, rle);
+  }
+  __device__ __forceinline__ void literals(uint32_t n) { x.literals(n); }
+  __device__ __forceinline__ void match(uint32_t offset, uint32_t ml) { x.match(offset, ml); }
+  __device__ __forceinline__ void sequence(uint32_t ll, uint32_t offset, uint32_t ml) {
+    if (ll) x.literals(ll);
+    x.match(offset, ml);
+  }
+  __device__ __forceinline__ void raw(uint32_t p, uint32_t size) { x.raw(p, size); }
+  __device__ __forceinline__ void rle_block(uint32_t byte, uint32_t size) { x.rle_block(byte, size); }
+  __device__ __forceinline__ bool frame_end(uint32_t frame_start, uint32_t want) { return x.frame_end(frame_start, want); }
+  __device__ __forceinline__ void drain() {}
+  __device__ __forceinline__ void finish() {}
+};
+
+constexpr uint32_t ZQ_N = 256;  // commands in flight
+constexpr uint32_t ZC_SEQ = 0, ZC_LITS = 1, ZC_SETLIT = 2, ZC_SETLIT2 = 3, ZC_RAW = 4, ZC_RLE = 5, ZC_FRAME = 6, ZC_DONE = 7;
+struct ZQueue {
+  u32x4 e[ZQ_N];
+  uint32_t head;     // commands written (the producer's)
+  uint32_t tail;     // commands taken (the consumer's): their slots are free
+  uint32_t done;     // commands carried out
+  uint32_t verdict;  // of the last checksum: 1 = fine
+};
+__device__ __forceinline__ uint32_t zq_load(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void zq_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// The producer's side (every lane of its wave alike; the other wave is resident in the same workgroup and takes commands
+// until it meets ZC_DONE, so a full queue empties and an awaited count is reached).
+struct ZPush {
+  static constexpr bool PIPELINED = true;
+  ZQueue& q;
+  uint32_t head, tail_seen;
+  __device__ __forceinline__ void push(u32x4 e) {
+    while (head - tail_seen >= ZQ_N) {
+      tail_seen = zq_load(&q.tail);
+      if (head - tail_seen >= ZQ_N) __builtin_amdgcn_s_sleep(2);
+    }
+    q.e[head & (ZQ_N - 1u)] = e;
+    ++head;
+    // (the count is made known every eighth command: making it known waits for the wave's LDS traffic)
+    if ((head & 7u) == 0u) zq_store(&q.head, head);
+  }
+  __device__ __forceinline__ void drain() {  // until everything handed over is carried out
+    zq_store(&q.head, head);
+    while (zq_load(&q.done) != head) __builtin_amdgcn_s_sleep(2);
+  }
+  __device__ __forceinline__ void set_literals(uint32_t lt, const PQD_GLOBAL uint8_t* base, uint32_t pos, uint32_t end, uint32_t rle) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    push(u32x4{ZC_SETLIT | (lt << 3) | (rle << 8), (uint32_t)b, (uint32_t)(b >> 32), pos});
+    push(u32x4{ZC_SETLIT2, end, 0u, 0u});
+  }
+  __device__ __forceinline__ void literals(uint32_t n) {
+    if (n) push(u32x4{ZC_LITS, n, 0u, 0u});
+  }
+  __device__ __forceinline__ void match(uint32_t offset, uint32_t ml) { push(u32x4{ZC_SEQ, 0u, ml, offset}); }
+  __device__ __forceinline__ void sequence(uint32_t ll, uint32_t offset, uint32_t ml) { push(u32x4{ZC_SEQ, ll, ml, offset}); }
+  __device__ __forceinline__ void raw(uint32_t p, uint32_t size) { push(u32x4{ZC_RAW, size, p, 0u}); }
+  __device__ __forceinline__ void rle_block(uint32_t byte, uint32_t size) { push(u32x4{ZC_RLE, size, byte, 0u}); }
+  __device__ __forceinline__ bool frame_end(uint32_t frame_start, uint32_t want) {
+    push(u32x4{ZC_FRAME, frame_start, want, 0u});
+    drain();
+    return zq_load(&q.verdict) != 0u;
+  }
+  __device__ __forceinline__ void finish() {
+    push(u32x4{ZC_DONE, 0u, 0u, 0u});
+    drain();
+  }
+};
+
+// The consumer's side: the second wave of the workgroup.
+__device__ __forceinline__ void zstd_consume(ZQueue& q, ZExec& x) {
+  uint32_t tail = 0, head_seen = 0, pend_lt = 0, pend_rle = 0, pend_pos = 0;
+  const PQD_GLOBAL uint8_t* pend_base = nullptr;
+  for (;;) {
+    while (head_seen == tail) {
+      head_seen = zq_load(&q.head);
+      if (head_seen == tail) __builtin_amdgcn_s_sleep(1);
+    }
+    const u32x4 e = q.e[tail & (ZQ_N - 1u)];
+    const uint32_t kind = uni(e.x) & 7u, a = uni(e.y), b = uni(e.z), c = uni(e.w), x0 = uni(e.x);
+    ++tail;
+    zq_store(&q.tail, tail);
+    if (kind == ZC_SEQ) {
+      if (a) x.literals(a);
+      x.match(c, b);
+    } else if (kind == ZC_LITS) {
+      x.literals(a);
+    } else if (kind == ZC_SETLIT) {
+      pend_lt = (x0 >> 3) & 3u;
+      pend_rle = (x0 >> 8) & 0xFFu;
+      pend_base = (const PQD_GLOBAL uint8_t*)(uintptr_t)(((uint64_t)b << 32) | a);
+      pend_pos = c;
+    } else if (kind == ZC_SETLIT2) {
+      x.set_literals(pend_lt, pend_base, pend_pos, a, pend_rle);
+    } else if (kind == ZC_RAW) {
+      x.raw(b, a);
+    } else if (kind == ZC_RLE) {
+      x.rle_block(b, a);
+    } else if (kind == ZC_FRAME) {
+      const bool fine = x.frame_end(a, b);
+      if (x.lane == 0) q.verdict = fine ? 1u : 0u;
+    }
+    if (kind == ZC_DONE || kind == ZC_FRAME) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zq_store(&q.done, tail);
+    if (kind == ZC_DONE) break;
+  }
+}
+
+// One page: the serial part.  sh, s_stage: the wave's LDS; sink: where the bytes are moved (above).
+template <class SINK>
+__device__ __forceinline__ void zstd_page(ZShared& sh, uint8_t* s_stage, const pqd_decompress_desc& d, SINK& sink, uint32_t lane, uint32_t page,
+                                          pqd_page_result* __restrict__ results) {
   if (lane < 36u) sh.ll_code[lane] = Z_LL_BASE[lane] | ((uint32_t)Z_LL_BITS[lane] << 24);
   if (lane < 53u) sh.ml_code[lane] = Z_ML_BASE[lane] | ((uint32_t)Z_ML_BITS[lane] << 24);
   InStage in;
@@ -467,10 +646,10 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
   in.start(0);
   in.win_at = 0x80000000u;
   in.win0 = in.win1 = 0;
-  OutRing out = {s_ring, (PQD_GLOBAL uint8_t*)d.dst, lane, ZS_RING - 1u};
   PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)d.dst;
   const uint32_t cap = d.dst_len, in_end = in.end;
   uint32_t ip = skew, op = 0;
+  uint32_t lit_busy_lo = cap;  // decoded literals that the other wave may not have read yet lie from here to the page's end
   int32_t status = PQD_OK;
 
   while (ip < in_end && status == PQD_OK) {  // frames one behind the other
@@ -518,12 +697,12 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
     uint64_t content = 0;
     for (uint32_t i = 0; i < fcs_bytes; ++i) content |= (uint64_t)zbyte(in, p++) << (8 * i);
     if (fcs_bytes == 2) content += 256;
-    __syncthreads();
+    lz_sync();
     sh.have_ll = sh.have_of = sh.have_ml = sh.huf_valid = 0;
     sh.rep[0] = 1;
     sh.rep[1] = 4;
     sh.rep[2] = 8;
-    __syncthreads();
+    lz_sync();
     const uint32_t frame_start = op;
     for (;;) {  // blocks
       if (in_end - p < 3u) {
@@ -538,12 +717,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           status = PQD_DECODE;
           break;
         }
-        for (uint32_t done = 0; done < size;) {
-          const uint32_t nn = size - done < 1900u ? size - done : 1900u;
-          in.reach(p + done);
-          out.literal(in, p + done, op + done, nn, 1900u);
-          done += nn;
-        }
+        sink.raw(p, size);
         op += size;
         p += size;
       } else if (type == 1) {  // one byte, repeated
@@ -551,11 +725,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           status = PQD_DECODE;
           break;
         }
-        const uint8_t v = (uint8_t)zbyte(in, p);
-        for (uint32_t i = lane; i < size; i += 64u) {
-          s_ring[(op + i) & (ZS_RING - 1u)] = v;
-          dst[op + i] = v;
-        }
+        sink.rle_block(zbyte(in, p), size);
         op += size;
         p += 1;
       } else if (type == 2) {
@@ -605,21 +775,16 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
         }
         uint32_t pos = hdr;  // within the block
         // where the literals are read from: the input (raw), one byte (RLE), or the page's end (Huffman)
-        InStage lits;
-        lits.lane = lane;
-        lits.lds = s_lits;
-        lits.cur = 0;
-        lits.win_at = 0x80000000u;
-        lits.win0 = lits.win1 = 0;
-        uint32_t lit_pos = 0;  // position of the next literal in `lits` coordinates
+        const PQD_GLOBAL uint8_t* lit_base = in.base;
+        uint32_t lit_end = 0;
+        uint32_t lit_pos = 0;  // position of the first literal, counted from lit_base
         uint32_t rle_byte = 0;
         if (lt == 0) {
           if (size - pos < regen) {
             status = PQD_DECODE;
             break;
           }
-          lits.base = in.base;
-          lits.end = in.end;
+          lit_end = in.end;
           lit_pos = p + pos;
           pos += regen;
         } else if (lt == 1) {
@@ -653,12 +818,24 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             status = PQD_DECODE;
             break;
           }
-          PQD_GLOBAL uint8_t* lit_out = dst + (cap - regen);
+          // (With a second wave moving the bytes, the blocks before this one may still be reading their literals at the
+          // page's end: this block's go in front of theirs while a whole block's output still fits in front of that,
+          // and the other wave is waited for otherwise.)
+          uint32_t lit_hi = cap;
+          if (SINK::PIPELINED) {
+            if (regen <= lit_busy_lo && (uint64_t)op + ZS_BLOCK_MAX + regen <= lit_busy_lo) {
+              lit_hi = lit_busy_lo;
+            } else {
+              sink.drain();
+            }
+            lit_busy_lo = lit_hi - regen;
+          }
+          PQD_GLOBAL uint8_t* lit_out = dst + (lit_hi - regen);
           const PQD_GLOBAL uint8_t* sbase = in.base + q;
           int32_t hst = PQD_OK;
           if (streams == 1) {
             if (lane == 0) sh.lane_status[0] = zhuf_stream(sh, sbase, left, lit_out, regen);
-            __syncthreads();
+            lz_sync();
             hst = sh.lane_status[0];
           } else {
             if (left < 6u) {
@@ -679,7 +856,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               const uint32_t cnt = lane < 3 ? each : regen - 3u * each;
               sh.lane_status[lane] = zhuf_stream(sh, sbase + 6u + off, len, lit_out + lane * each, cnt);
             }
-            __syncthreads();
+            lz_sync();
             // the first stream that fails decides (the streams are decoded in order by the format's decoder)
             for (int k = 3; k >= 0; --k) hst = sh.lane_status[k] != PQD_OK ? sh.lane_status[k] : hst;
           }
@@ -691,31 +868,12 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           // the decoded literals: stored by lanes of this wave, read back through memory
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          lits.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)lit_out & ~(uintptr_t)15);
+          lit_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)lit_out & ~(uintptr_t)15);
           lit_pos = (uint32_t)((uintptr_t)lit_out & 15u);
-          lits.end = lit_pos + regen;
+          lit_end = lit_pos + regen;
         }
-        if (lt != 1) lits.start(lit_pos / LZ_CHUNK);
+        sink.set_literals(lt, lit_base, lit_pos, lit_end, rle_byte);
         uint32_t lit_left = regen;
-        // copies `n` literals to the output
-        auto put_literals = [&](uint32_t n) {
-          if (lt == 1) {
-            for (uint32_t i = lane; i < n; i += 64u) {
-              s_ring[(op + i) & (ZS_RING - 1u)] = (uint8_t)rle_byte;
-              dst[op + i] = (uint8_t)rle_byte;
-            }
-          } else {
-            for (uint32_t done = 0; done < n;) {
-              const uint32_t nn = n - done < 1900u ? n - done : 1900u;
-              lits.reach(lit_pos + done);
-              out.literal(lits, lit_pos + done, op + done, nn, 1900u);
-              done += nn;
-            }
-          }
-          lit_pos += n;
-          lit_left -= n;
-          op += n;
-        };
         // ---- sequences
         if (size - pos < 1u) {
           status = PQD_DECODE;
@@ -765,7 +923,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             status = PQD_DECODE;
             break;
           }
-          __syncthreads();
+          lz_sync();
           const uint32_t sn = size - pos;
           if (sn == 0) {
             status = PQD_DECODE;
@@ -847,10 +1005,10 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
               break;
             }
             ZS_STAMP(0)
-            put_literals(ll);
-            ZS_STAMP(1)
             // matches reach back into the frame only
-            if (offset == 0u || offset > op - frame_start || ml > cap - op) {
+            if (offset == 0u || offset > op + ll - frame_start || ml > cap - op - ll) {
+              sink.literals(ll);  // (the literals in front of the match that fails are delivered)
+              op += ll;
               status = PQD_DECODE;
               break;
             }
@@ -859,23 +1017,21 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
             zfar[1] += offset > 4u * ZS_RING ? 1u : 0u;
             zfar[2] += offset < 64u ? 1u : 0u;
             zfar[3] += ll == 0u ? 1u : 0u;
-            const uint64_t zm0 = __builtin_readcyclecounter();
 #endif
-            out.match(op, offset, ml);
-#ifdef ZS_PROF
-            if (offset > ZS_RING) zfar_cycles += __builtin_readcyclecounter() - zm0;
-#endif
+            sink.sequence(ll, offset, ml);
+            lit_left -= ll;
+            op += ll;
             op += ml;
             ZS_STAMP(2)
           }
 #ifdef ZS_PROF
           if (page == 0 && lane == 0) printf("block: %u sequences, cycles per sequence: decode %llu, literals %llu, match %llu; offsets beyond the ring %u (%llu cycles each), beyond four rings %u, below 64: %u, without literals %u\n", n_seq, zp[0] / n_seq, zp[1] / n_seq, zp[2] / n_seq, zfar[0], zfar[0] ? zfar_cycles / zfar[0] : 0ull, zfar[1], zfar[2], zfar[3]);
 #endif
-          __syncthreads();
+          lz_sync();
           sh.rep[0] = rep0;
           sh.rep[1] = rep1;
           sh.rep[2] = rep2;
-          __syncthreads();
+          lz_sync();
           if (status != PQD_OK) break;
           if (bit != bit_end) {
             status = PQD_DECODE;
@@ -889,7 +1045,8 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
           status = PQD_DECODE;
           break;
         }
-        put_literals(lit_left);
+        sink.literals(lit_left);
+        op += lit_left;
         p += size;
       } else {
         status = PQD_DECODE;
@@ -908,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
         break;
       }
       const uint32_t want = zbyte(in, p) | (zbyte(in, p + 1) << 8) | (zbyte(in, p + 2) << 16) | (zbyte(in, p + 3) << 24);
-      if (uni((uint32_t)zxxh64(dst + frame_start, op - frame_start, lane)) != want) {
+      if (!sink.frame_end(frame_start, want)) {
         status = PQD_DECODE;
         break;
       }
@@ -916,6 +1073,7 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
     }
     ip = p;
   }
+  sink.finish();
   if (status == PQD_OK && op != cap) status = PQD_DECODE;  // the page header announced cap bytes
   if (lane == 0) {
     pqd_page_result r = {status, op, ip - skew, 0u};
@@ -923,9 +1081,57 @@ __global__ __launch_bounds__(64) void k_zstd_pages(const pqd_decompress_desc* __
   }
 }
 
+// PIPE false: one wave per page does everything (calls of many pages: the waves of other pages fill the gaps).  PIPE
+// true: two waves per page, the first decodes, the second moves the bytes.
+template <bool PIPE>
+__global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decompress_desc* __restrict__ descs,
+                                                                pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  __shared__ ZShared sh;
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZS_RING];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_lits[LZ_STAGE];
+  __shared__ ZQueue queue;
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_decompress_desc d = descs[page];
+  if (d.codec != (uint32_t)PQD_CODEC_ZSTD) return;  // another kernel's page
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (d.src_len > 0x7fffffffu) {
+    if (threadIdx.x == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  ZExec exec;
+  exec.init(s_ring, s_lits, d, lane);
+  if constexpr (PIPE) {
+    if (threadIdx.x == 0) queue.head = queue.tail = queue.done = queue.verdict = 0u;
+    __syncthreads();  // (the one barrier of the workgroup: the two waves go separate ways behind it)
+    if (wave == 1u) {
+      zstd_consume(queue, exec);
+    } else {
+      ZPush sink = {queue, 0u, 0u};
+      zstd_page(sh, s_stage, d, sink, lane, page, results);
+    }
+  } else {
+    ZDirect sink = {exec};
+    zstd_page(sh, s_stage, d, sink, lane, page, results);
+  }
+}
+
+// calls of at most this many pages get two waves per page
+constexpr uint32_t ZS_PIPE_MAX_PAGES = 768;
+
 hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_zstd_pages, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  const char* env = getenv("PQD_ZSTD_WAVES");  // 1 / 2: fixes the waves per page (testing)
+  const int forced = env ? atoi(env) : 0;
+  const bool pipe = forced == 2 || (forced != 1 && n_pages <= ZS_PIPE_MAX_PAGES);
+  if (pipe)
+    hipLaunchKernelGGL(k_zstd_pages<true>, dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
+  else
+    hipLaunchKernelGGL(k_zstd_pages<false>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
   return hipGetLastError();
 }
 

@@ -11,6 +11,15 @@ constexpr uint32_t LZ_STAGE = 2 * LZ_CHUNK;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// An order for the LDS accesses of ONE wave's lanes (the kernels that use this header run a page's serial parts in one
+// wave; where a second wave of the workgroup does other work, a workgroup barrier would be wrong).  LDS instructions of a
+// wave complete in order; the fences keep the compiler from moving accesses across.
+__device__ __forceinline__ void lz_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // (Memory is addressed through global-space pointers: see PQD_GLOBAL.)
 struct InStage {
   const PQD_GLOBAL uint8_t* base;  // the source, rounded down to 16 bytes; positions below count from here
@@ -36,23 +45,23 @@ struct InStage {
     u32x4 a0, a1, b0, b1;
     load(c, a0, a1);
     load(c + 1, b0, b1);
-    __syncthreads();
+    lz_sync();
     put(c, a0, a1);
     put(c + 1, b0, b1);
     load(c + 2, pre0, pre1);
     cur = c;
-    __syncthreads();
+    lz_sync();
   }
   // makes the chunk of `pos` and the one behind it readable
   __device__ __forceinline__ void reach(uint32_t pos) {
     const uint32_t c = pos / LZ_CHUNK;
     if (c == cur) return;
     if (c == cur + 1) {
-      __syncthreads();
+      lz_sync();
       put(cur + 2, pre0, pre1);
       cur = c;
       load(cur + 2, pre0, pre1);
-      __syncthreads();
+      lz_sync();
     } else {
       start(c);
     }

@@ -569,6 +569,15 @@ def test_gpu_lz_pages_with_four_and_eight_waves(orc, monkeypatch, codec_name, wa
 
 
 @pytest.mark.gpu
+def test_gpu_zstd_pages_with_one_wave(orc, monkeypatch):
+    """The ZSTD kernel gives a page two waves in calls of few pages (the first decodes, the second moves the bytes:
+    every test here), one wave in larger ones: the same streams with one wave."""
+    monkeypatch.setenv("PQD_ZSTD_WAVES", "1")
+    test_gpu_decompresses_library_streams_and_pages(orc, "ZSTD")
+    test_gpu_damaged_streams(orc, "ZSTD")
+
+
+@pytest.mark.gpu
 def test_gpu_snappy_far_copies_in_front_of_literals(orc):
     import torch
     import parquet_java_amd as pq
