@@ -533,7 +533,7 @@ struct ZDirect {
   __device__ __forceinline__ void rle_block(uint32_t byte, uint32_t size) { x.rle_block(byte, size); }
   __device__ __forceinline__ bool frame_end(uint32_t frame_start, uint32_t want) { return x.frame_end(frame_start, want); }
   __device__ __forceinline__ void drain() {}
-  __device__ __forceinline__ void finish() {}
+  __device__ __forceinline__ bool finish() { return true; }
 };
 
 constexpr uint32_t ZQ_N = 256;  // commands in flight
@@ -544,7 +544,11 @@ struct ZQueue {
   uint32_t tail;     // commands taken (the consumer's): their slots are free
   uint32_t done;     // commands carried out
   uint32_t verdict;  // of the last checksum: 1 = fine
+  uint32_t abort;    // a side has waited for the other beyond ZQ_PATIENCE: both give the page up (it reports PQD_DECODE)
 };
+// Rounds of waiting (128 cycles each) a side puts up with: about a second.  Nothing known makes a side wait that long; the
+// limit is there so that a mistake ends as a failed page, not as waves that never finish.
+constexpr uint32_t ZQ_PATIENCE = 1u << 24;
 __device__ __forceinline__ uint32_t zq_load(const uint32_t* p) { return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void zq_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -554,19 +558,33 @@ struct ZPush {
   static constexpr bool PIPELINED = true;
   ZQueue& q;
   uint32_t head, tail_seen;
+  bool aborted;
   __device__ __forceinline__ void push(u32x4 e) {
-    while (head - tail_seen >= ZQ_N) {
+    uint32_t rounds = 0;
+    while (head - tail_seen >= ZQ_N && !aborted) {
       tail_seen = zq_load(&q.tail);
-      if (head - tail_seen >= ZQ_N) __builtin_amdgcn_s_sleep(2);
+      if (head - tail_seen >= ZQ_N) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++rounds > ZQ_PATIENCE || zq_load(&q.abort)) give_up();
+      }
     }
+    if (aborted) return;
     q.e[head & (ZQ_N - 1u)] = e;
     ++head;
     // (the count is made known every eighth command: making it known waits for the wave's LDS traffic)
     if ((head & 7u) == 0u) zq_store(&q.head, head);
   }
+  __device__ __forceinline__ void give_up() {
+    aborted = true;
+    zq_store(&q.abort, 1u);
+  }
   __device__ __forceinline__ void drain() {  // until everything handed over is carried out
     zq_store(&q.head, head);
-    while (zq_load(&q.done) != head) __builtin_amdgcn_s_sleep(2);
+    uint32_t rounds = 0;
+    while (!aborted && zq_load(&q.done) != head) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++rounds > ZQ_PATIENCE || zq_load(&q.abort)) give_up();
+    }
   }
   __device__ __forceinline__ void set_literals(uint32_t lt, const PQD_GLOBAL uint8_t* base, uint32_t pos, uint32_t end, uint32_t rle) {
     const uint64_t b = (uint64_t)(uintptr_t)base;
@@ -583,11 +601,13 @@ struct ZPush {
   __device__ __forceinline__ bool frame_end(uint32_t frame_start, uint32_t want) {
     push(u32x4{ZC_FRAME, frame_start, want, 0u});
     drain();
-    return zq_load(&q.verdict) != 0u;
+    return !aborted && zq_load(&q.verdict) != 0u;
   }
-  __device__ __forceinline__ void finish() {
+  // false: the page was given up
+  __device__ __forceinline__ bool finish() {
     push(u32x4{ZC_DONE, 0u, 0u, 0u});
     drain();
+    return !aborted;
   }
 };
 
@@ -596,10 +616,20 @@ __device__ __forceinline__ void zstd_consume(ZQueue& q, ZExec& x) {
   uint32_t tail = 0, head_seen = 0, pend_lt = 0, pend_rle = 0, pend_pos = 0;
   const PQD_GLOBAL uint8_t* pend_base = nullptr;
   for (;;) {
+    uint32_t rounds = 0;
+    bool given_up = false;
     while (head_seen == tail) {
       head_seen = zq_load(&q.head);
-      if (head_seen == tail) __builtin_amdgcn_s_sleep(1);
+      if (head_seen == tail) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++rounds > ZQ_PATIENCE || zq_load(&q.abort)) {
+          zq_store(&q.abort, 1u);
+          given_up = true;
+          break;
+        }
+      }
     }
+    if (given_up) break;
     const u32x4 e = q.e[tail & (ZQ_N - 1u)];
     const uint32_t kind = uni(e.x) & 7u, a = uni(e.y), b = uni(e.z), c = uni(e.w), x0 = uni(e.x);
     ++tail;
@@ -1073,7 +1103,7 @@ __device__ __forceinline__ void zstd_page(ZShared& sh, uint8_t* s_stage, const p
     }
     ip = p;
   }
-  sink.finish();
+  if (!sink.finish()) status = PQD_DECODE;
   if (status == PQD_OK && op != cap) status = PQD_DECODE;  // the page header announced cap bytes
   if (lane == 0) {
     pqd_page_result r = {status, op, ip - skew, 0u};
@@ -1106,12 +1136,12 @@ __global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decomp
   ZExec exec;
   exec.init(s_ring, s_lits, d, lane);
   if constexpr (PIPE) {
-    if (threadIdx.x == 0) queue.head = queue.tail = queue.done = queue.verdict = 0u;
+    if (threadIdx.x == 0) queue.head = queue.tail = queue.done = queue.verdict = queue.abort = 0u;
     __syncthreads();  // (the one barrier of the workgroup: the two waves go separate ways behind it)
     if (wave == 1u) {
       zstd_consume(queue, exec);
     } else {
-      ZPush sink = {queue, 0u, 0u};
+      ZPush sink = {queue, 0u, 0u, false};
       zstd_page(sh, s_stage, d, sink, lane, page, results);
     }
   } else {
