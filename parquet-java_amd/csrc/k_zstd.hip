@@ -449,8 +449,8 @@ struct ZExec {
   const PQD_GLOBAL uint8_t* in_base;  // the input from its aligned base (raw blocks)
   uint32_t op, lit_pos, lt, rle_byte, lane;
 
-  __device__ __forceinline__ void init(uint8_t* ring, uint8_t* lit_stage, const pqd_decompress_desc& d, uint32_t lane_) {
-    out = OutRing{ring, (PQD_GLOBAL uint8_t*)d.dst, lane_, ZS_RING - 1u};
+  __device__ __forceinline__ void init(uint8_t* ring, uint32_t ring_bytes, uint8_t* lit_stage, const pqd_decompress_desc& d, uint32_t lane_) {
+    out = OutRing{ring, (PQD_GLOBAL uint8_t*)d.dst, lane_, ring_bytes - 1u};
     in_base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
     lane = lane_;
     lits.lane = lane_;
@@ -1113,11 +1113,13 @@ __device__ __forceinline__ void zstd_page(ZShared& sh, uint8_t* s_stage, const p
 
 // PIPE false: one wave per page does everything (calls of many pages: the waves of other pages fill the gaps).  PIPE
 // true: two waves per page, the first decodes, the second moves the bytes.
-template <bool PIPE>
+// RING: bytes of output kept in LDS for the matches (farther ones are read back from memory behind a wait for the
+// wave's stores): 8 KiB where seven pages share a CU, more where fewer do.
+template <bool PIPE, uint32_t RING>
 __global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decompress_desc* __restrict__ descs,
                                                                 pqd_page_result* __restrict__ results, uint32_t n_pages) {
   __shared__ ZShared sh;
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZS_RING];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[RING];
   __shared__ __attribute__((aligned(16))) uint8_t s_stage[LZ_STAGE];
   __shared__ __attribute__((aligned(16))) uint8_t s_lits[LZ_STAGE];
   __shared__ ZQueue queue;
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decomp
     return;
   }
   ZExec exec;
-  exec.init(s_ring, s_lits, d, lane);
+  exec.init(s_ring, RING, s_lits, d, lane);
   if constexpr (PIPE) {
     if (threadIdx.x == 0) queue.head = queue.tail = queue.done = queue.verdict = queue.abort = 0u;
     __syncthreads();  // (the one barrier of the workgroup: the two waves go separate ways behind it)
@@ -1150,18 +1152,20 @@ __global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decomp
   }
 }
 
-// calls of at most this many pages get two waves per page
-constexpr uint32_t ZS_PIPE_MAX_PAGES = 768;
+// calls of at most this many pages get two waves per page, and the fewer the pages the more of the output in LDS
+constexpr uint32_t ZS_PIPE_MAX_PAGES = 768, ZS_BIG_RING_MAX_PAGES = 512;
 
 hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
   const char* env = getenv("PQD_ZSTD_WAVES");  // 1 / 2: fixes the waves per page (testing)
   const int forced = env ? atoi(env) : 0;
   const bool pipe = forced == 2 || (forced != 1 && n_pages <= ZS_PIPE_MAX_PAGES);
-  if (pipe)
-    hipLaunchKernelGGL(k_zstd_pages<true>, dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
+  if (pipe && n_pages <= ZS_BIG_RING_MAX_PAGES)
+    hipLaunchKernelGGL((k_zstd_pages<true, 32768u>), dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
+  else if (pipe)
+    hipLaunchKernelGGL((k_zstd_pages<true, 16384u>), dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
   else
-    hipLaunchKernelGGL(k_zstd_pages<false>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_zstd_pages<false, ZS_RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
   return hipGetLastError();
 }
 
