@@ -31,6 +31,7 @@
 // Measured and dropped: an element per lane copying its bytes in order, with an LDS ring of the last 32 KiB of output
 // (fewer instructions when matches reach far back, three times slower when most matches read what the 64 elements
 // of their own batch write, as in columns of small numbers and repetitive text).
+#include <cstdio>
 #include <cstdlib>
 
 #include "pqd_device.hpp"
@@ -55,37 +56,110 @@ constexpr uint32_t LW_HUGE = 1u << 18;  // elements from this length on are left
 constexpr uint32_t LW_TILE = 4096;   // output bytes per tile
 constexpr uint32_t LW_ELEMS = 1408;  // elements per window at most (Snappy: 2 bytes each; LZ4: 2 per 3 bytes)
 constexpr uint32_t LW_FAIL = 0x80000000u, LW_NONE = 0xFFFFFFFFu, LW_LIT = 0x80000000u;
-constexpr uint32_t LW_HAS = 0x80000000u;  // a tile cell that holds its byte
+constexpr uint16_t LW_HAS = 0x8000u;  // a tile cell that holds its byte
 #ifndef LW_UNROLL
 #define LW_UNROLL 4u
 #endif
-// Waves per page: four when thousands of pages are in flight (the parse is one wave's, and seven pages a CU keep its
-// SIMDs busy), eight or sixteen when a call has few pages (the tiles' bytes are shared out among more lanes; measured
-// on 1 MiB pages of text: 256 pages 32 / 39 / 45 GB/s with 4 / 8 / 16 waves, 1792 pages 99 / 66 / 45).
-constexpr uint32_t LW_FEW_PAGES = 384, LW_SOME_PAGES = 768;
+// Kernel and waves per page by the size of the call.  A page's time is its two serial chains (the parse: one wave; the
+// pointer rounds of its tiles), not the CU's throughput: calls of at most 768 pages let the first wave parse the next
+// window while the others execute the one before (k_lz_pipe_pages; 52 KB of LDS: three pages a CU) with 16 / 8 / 4
+// waves in calls of at most 256 / 512 / 768 pages; larger ones take four waves that parse, then execute (22.5 KB: up
+// to seven pages a CU).  1 MiB pages of text, Snappy / LZ4: 256 pages 61 / 52 GB/s (one after the other: 45 / 33),
+// 512 pages 89 / 86 (68 / 56), 768 pages 95 / 95 (82 / 70), 1280 pages 115 / 100.
+constexpr uint32_t LW_PIPE16_PAGES = 256, LW_PIPE8_PAGES = 512, LW_PIPE4_PAGES = 768;
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // window byte q in LDS (no padding between the lanes' segments: the instructions of an address with padding cost more
 // than the bank conflicts of one without)
 __device__ __forceinline__ uint32_t lw_at(uint32_t q) { return q; }
 
-struct LwLds {
-  __attribute__((aligned(16))) uint8_t win[LW_WIN + LW_SLACK + 32];
-  union {
-    struct {  // parse: per place .x = where the chain from it leaves the segment (LW_FAIL: it stops inside),
-              // .y = elements on the way << 24 | output bytes of the sequences on the way
-      u32x2 place[64 * 33];
-    } p;
-    struct {  // execute
-      uint32_t cell[LW_TILE];
-    } x;
-  } u;
+// What the parse of a window tells its execution.
+struct LwWindow {
+  uint32_t w0, staged;    // the stream bytes in LDS: [w0, staged)
+  uint32_t o0, out_end;   // the output of the window's elements: [o0, out_end)
+  uint32_t n_elems, new_ip;
+  uint32_t stopped, pad;  // stopped: the chain ended in front of a sequence that is taken by itself
+};
+
+struct LwElems {
   uint32_t e_out[LW_ELEMS + 8];  // output position of element i; [n] = where the window's output ends
   uint32_t e_src[LW_ELEMS + 8];  // LW_LIT | stream position of a literal's first byte, or a match's offset
-  uint32_t t_lo[64], t_hi[64];   // per 64 bytes of the tile: the bytes at which an element starts
-  uint32_t t_before[64];         // the element that holds the byte in front of those 64
-  uint32_t n_elems, new_ip, out_end, e_lo, flag[3];  // what the first wave tells the others
-  bool stopped;
+};
+
+struct LwTiles {
+  uint32_t t_lo[64], t_hi[64];  // per 64 bytes of the tile: the bytes at which an element starts
+  uint32_t t_before[64];        // the element that holds the byte in front of those 64
+  uint32_t flag[3];
+};
+
+// One window at a time, parsed and then executed by the same waves (22.5 KB: seven pages a CU; the table of places is
+// done with when the list of elements is written).
+struct LwLds {
+  __attribute__((aligned(16))) uint8_t win_[LW_WIN + LW_SLACK + 32];
+  union {
+    // parse: per place .x = where the chain from it leaves the segment (LW_FAIL: it stops inside),
+    // .y = elements on the way << 24 | output bytes of the sequences on the way
+    u32x2 place[64 * 33];
+    struct {  // the elements, and the tile they are executed in
+      LwElems e;
+      __attribute__((aligned(16))) uint16_t cell[LW_TILE];
+    } x;
+  } u;
+  LwTiles t;
+  LwWindow w_;
+  uint32_t after_ip, after_op, after_failed;  // where a sequence taken by itself ended
+  __device__ __forceinline__ uint8_t* win(uint32_t) { return win_; }
+  __device__ __forceinline__ u32x2* place() { return u.place; }
+  __device__ __forceinline__ LwElems& elems(uint32_t) { return u.x.e; }
+  __device__ __forceinline__ uint16_t* cell() { return u.x.cell; }
+  __device__ __forceinline__ LwWindow& window(uint32_t) { return w_; }
+};
+
+// Two windows: the first wave parses one while the others execute the one before it (50 KB: three pages a CU).
+struct LwPipeLds {
+  __attribute__((aligned(16))) uint8_t win_[2][LW_WIN + LW_SLACK + 32];
+  u32x2 place_[64 * 33];
+  LwElems e_[2];
+  __attribute__((aligned(16))) uint16_t cell_[LW_TILE];
+  LwTiles t;
+  LwWindow w_[2];
+  uint32_t after_ip, after_op, after_failed;
+  uint32_t arrived, abort;  // the executing waves' barrier: arrivals so far; a wait that ran out of patience
+  __device__ __forceinline__ uint8_t* win(uint32_t s) { return win_[s]; }
+  __device__ __forceinline__ u32x2* place() { return place_; }
+  __device__ __forceinline__ LwElems& elems(uint32_t s) { return e_[s]; }
+  __device__ __forceinline__ uint16_t* cell() { return cell_; }
+  __device__ __forceinline__ LwWindow& window(uint32_t s) { return w_[s]; }
+};
+
+// The barrier between the steps of a tile.  All waves of the workgroup execute: the hardware's.
+struct LwAllWaves {
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+  __device__ __forceinline__ bool aborted() const { return false; }
+};
+// All waves but the parsing one execute: every wave adds one to a counter in LDS and waits until all have (the counter
+// only grows; the comparison survives its wrap).  The waves of a workgroup are resident together, so the wait ends; a
+// wait of more than LW_PATIENCE looks nevertheless gives the page up (PQD_DECODE) rather than never ending.
+constexpr uint32_t LW_PATIENCE = 1u << 24;
+struct LwExecWaves {
+  uint32_t* arrived;
+  uint32_t* abort;
+  uint32_t target, n_waves, lane;
+  __device__ __forceinline__ void sync() {
+    target += n_waves;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t looks = 0;
+    while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
+      if (++looks > LW_PATIENCE || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ bool aborted() const { return __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; }
 };
 
 #ifdef LW_PROF
@@ -187,160 +261,168 @@ __device__ __forceinline__ LwSeq lw_parse(const uint8_t* win, uint32_t w0, uint3
   return s;
 }
 
-// One window: the sequences from stream position ip on, as far as the window (or the chain of well-formed
-// sequences) goes; their output is written.  ip / op move behind them.  Returns true when the chain stopped in
-// front of a sequence that the caller has to take by itself.  All WAVES waves of the workgroup call it: the parse
-// is the first wave's, the tiles' bytes are shared out among all of them.
-template <int CODEC, uint32_t WAVES>
-__device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op,
-                                          uint32_t in_end, uint32_t cap, uint32_t tid LW_PROF_ARGS) {
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
-  const uint32_t w0 = ip;
-  const uint32_t staged = in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
-  // ---- the window -> LDS
-  __syncthreads();
-  for (uint32_t t = tid * 16u; t < staged - w0; t += WAVES * 1024u) {
+// stream bytes [w0, staged) -> LDS; thread k of the n that share the work passes first = 16 k, stride = 16 n
+__device__ __forceinline__ void lw_stage(uint8_t* win, const PQD_GLOBAL uint8_t* src, uint32_t w0, uint32_t staged, uint32_t first, uint32_t stride) {
+  for (uint32_t t = first; t < staged - w0; t += stride) {
     if (t + 16u <= staged - w0) {
       u32x4 v;
       __builtin_memcpy(&v, (const uint8_t*)(src + w0 + t), 16);
-      *reinterpret_cast<u32x4*>(L.win + t) = v;
+      *reinterpret_cast<u32x4*>(win + t) = v;
     } else {
-      for (uint32_t k = 0; t + k < staged - w0; ++k) L.win[lw_at(t + k)] = src[w0 + t + k];
+      for (uint32_t k = 0; t + k < staged - w0; ++k) win[lw_at(t + k)] = src[w0 + t + k];
     }
   }
-  __syncthreads();
-  LW_STAMP(0)
-  if (wave == 0) {
-    // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither
-    // of the two continues at the other; the one exception is dealt with below)
-    const uint32_t seg = w0 + lane * 32u;
-    for (int pl = 31; pl >= 1; pl -= 2) {
-      LwSeq s[2];
-      uint32_t j[2];
-      u32x2 at_j[2];
+}
+
+__device__ __forceinline__ uint32_t lw_staged_end(uint32_t w0, uint32_t in_end) {
+  return in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
+}
+
+// The parse of one window, by one wave: the sequences from stream position ip on (output position op), as far as the
+// window (or the chain of well-formed sequences) goes, become the slot's list of elements and its LwWindow record.
+// The window's bytes lie in L.win(slot).
+template <int CODEC, class LDS>
+__device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap,
+                                                uint32_t lane LW_PROF_ARGS) {
+  const uint32_t w0 = ip, staged = lw_staged_end(w0, in_end);
+  const uint8_t* win = L.win(slot);
+  u32x2* place = L.place();
+  LwElems& E = L.elems(slot);
+  // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither
+  // of the two continues at the other; the one exception is dealt with below)
+  const uint32_t seg = w0 + lane * 32u;
+  for (int pl = 31; pl >= 1; pl -= 2) {
+    LwSeq s[2];
+    uint32_t j[2];
+    u32x2 at_j[2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s[u] = lw_parse<CODEC>(L.win, w0, seg + (uint32_t)(pl - u), in_end, staged);
-        s[u].ok = s[u].ok && s[u].lit_len < LW_HUGE && s[u].mlen < LW_HUGE;  // (a segment's sum stays below 2^24)
-        // a sequence that ends inside the segment continues with the entry of the place it ends at (the look-up is made
-        // in any case, at a place inside the segment)
-        j[u] = s[u].ok && s[u].next < seg + 32u ? s[u].next - seg : 31u;
-      }
+    for (int u = 0; u < 2; ++u) {
+      s[u] = lw_parse<CODEC>(win, w0, seg + (uint32_t)(pl - u), in_end, staged);
+      s[u].ok = s[u].ok && s[u].lit_len < LW_HUGE && s[u].mlen < LW_HUGE;  // (a segment's sum stays below 2^24)
+      // a sequence that ends inside the segment continues with the entry of the place it ends at (the look-up is made
+      // in any case, at a place inside the segment)
+      j[u] = s[u].ok && s[u].next < seg + 32u ? s[u].next - seg : 31u;
+    }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) at_j[u] = L.u.p.place[lane * 33u + j[u]];
-      u32x2 e[2];
+    for (int u = 0; u < 2; ++u) at_j[u] = place[lane * 33u + j[u]];
+    u32x2 e[2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bool inside = s[u].ok && s[u].next < seg + 32u;
-        // (LZ4's last sequence may be its token alone: the lower place of the pair then continues at the upper one, whose
-        // entry is not in the table yet)
-        if (u == 1 && j[1] == (uint32_t)pl) at_j[1] = e[0];
-        e[u].x = !s[u].ok ? LW_FAIL : inside ? at_j[u].x : s[u].next;
-        e[u].y = !s[u].ok ? 0u : s[u].lit_len + s[u].mlen + (((s[u].lit_len ? 1u : 0u) + (s[u].mlen ? 1u : 0u)) << 24) + (inside ? at_j[u].y : 0u);
-        L.u.p.place[lane * 33u + (uint32_t)(pl - u)] = e[u];
-      }
+    for (int u = 0; u < 2; ++u) {
+      const bool inside = s[u].ok && s[u].next < seg + 32u;
+      // (LZ4's last sequence may be its token alone: the lower place of the pair then continues at the upper one, whose
+      // entry is not in the table yet)
+      if (u == 1 && j[1] == (uint32_t)pl) at_j[1] = e[0];
+      e[u].x = !s[u].ok ? LW_FAIL : inside ? at_j[u].x : s[u].next;
+      e[u].y = !s[u].ok ? 0u : s[u].lit_len + s[u].mlen + (((s[u].lit_len ? 1u : 0u) + (s[u].mlen ? 1u : 0u)) << 24) + (inside ? at_j[u].y : 0u);
+      place[lane * 33u + (uint32_t)(pl - u)] = e[u];
     }
-    __builtin_amdgcn_wave_barrier();
-    LW_STAMP(1)
-    // ---- 2. the chain through the window
-    uint32_t entry = LW_NONE, first_elem = 0;
-    uint64_t first_out = 0;
-    {
-      uint32_t at = ip, elems = 0;
-      uint64_t made = op;
-      uint32_t dog1 = 0;
-      while (at < w0 + LW_WIN && at < in_end && made <= cap) {
-        LW_DOG(dog1, 1)
-        const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
-        const u32x2 e = L.u.p.place[k * 33u + pl];
-        const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
-        if (lane == k) {
-          entry = at;
-          first_elem = elems;
-          first_out = made;
-        }
-        elems += m >> 24;
-        made += m & 0xFFFFFFu;
-        if (ex & LW_FAIL) break;
-        at = ex;
-      }
-    }
-    LW_STAMP(2)
-    // ---- 3. this lane's elements
-    uint32_t mine = 0, end = 0;
-    uint64_t out_end = 0;
-    bool stop = false;
-    if (entry != LW_NONE) {
-      uint32_t q = entry, i = first_elem;
-      uint64_t o = first_out;
-      uint32_t dog2 = 0;
-      while (q < seg + 32u && q < in_end) {
-        LW_DOG(dog2, 2)
-        const LwSeq s = lw_parse<CODEC>(L.win, w0, q, in_end, staged);
-        if (!s.ok || s.lit_len >= LW_HUGE || s.mlen >= LW_HUGE || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
-          stop = true;
-          break;
-        }
-        if (s.lit_len) {
-          L.e_out[i] = (uint32_t)o;
-          L.e_src[i] = LW_LIT | s.lit_pos;
-          o += s.lit_len;
-          ++i;
-        }
-        if (s.mlen) {
-          L.e_out[i] = (uint32_t)o;
-          L.e_src[i] = s.offset;
-          o += s.mlen;
-          ++i;
-        }
-        q = s.next;
-      }
-      mine = i - first_elem;
-      end = q;
-      out_end = o;
-    }
-    // lanes behind one that stopped were entered for nothing
-    const uint64_t stops = __builtin_amdgcn_ballot_w64(stop);
-    if (stops && lane > (uint32_t)__builtin_ctzll(stops)) {
-      entry = LW_NONE;
-      mine = 0;
-    }
-    const uint64_t entered = __builtin_amdgcn_ballot_w64(entry != LW_NONE);
-    const uint32_t n = lw_uni((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(mine), 63));
-    const uint32_t last = entered ? lw_uni(63u - (uint32_t)__builtin_clzll(entered)) : 0u;
-    const uint32_t stream_end = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)last);
-    const uint32_t output_end = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)out_end, (int)last);  // (at most cap)
-    if (lane == 0) {
-      L.e_out[n] = output_end;
-      L.n_elems = entered ? n : 0u;
-      L.new_ip = entered ? stream_end : ip;  // (not entered cannot be: ip lies in the window)
-      L.out_end = entered ? output_end : op;
-      L.stopped = !entered || stops != 0;
-      L.e_lo = 0;
-    }
-    LW_STAMP(3)
   }
-  __syncthreads();
-  const uint32_t n_elems = L.n_elems, new_ip = L.new_ip, o1 = L.out_end;
-  const bool stopped = L.stopped;
-  // ---- 4. the output, tile by tile
-  const uint32_t o0 = op;
-  uint32_t* cell = L.u.x.cell;
+  __builtin_amdgcn_wave_barrier();
+  LW_STAMP(1)
+  // ---- 2. the chain through the window
+  uint32_t entry = LW_NONE, first_elem = 0;
+  uint64_t first_out = 0;
+  {
+    uint32_t at = ip, elems = 0;
+    uint64_t made = op;
+    uint32_t dog1 = 0;
+    while (at < w0 + LW_WIN && at < in_end && made <= cap) {
+      LW_DOG(dog1, 1)
+      const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
+      const u32x2 e = place[k * 33u + pl];
+      const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
+      if (lane == k) {
+        entry = at;
+        first_elem = elems;
+        first_out = made;
+      }
+      elems += m >> 24;
+      made += m & 0xFFFFFFu;
+      if (ex & LW_FAIL) break;
+      at = ex;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // (where the list below takes the table's room)
+  LW_STAMP(2)
+  // ---- 3. this lane's elements
+  uint32_t mine = 0, end = 0;
+  uint64_t out_end = 0;
+  bool stop = false;
+  if (entry != LW_NONE) {
+    uint32_t q = entry, i = first_elem;
+    uint64_t o = first_out;
+    uint32_t dog2 = 0;
+    while (q < seg + 32u && q < in_end) {
+      LW_DOG(dog2, 2)
+      const LwSeq s = lw_parse<CODEC>(win, w0, q, in_end, staged);
+      if (!s.ok || s.lit_len >= LW_HUGE || s.mlen >= LW_HUGE || (s.mlen && s.offset > o + s.lit_len) || o + s.lit_len + s.mlen > cap) {
+        stop = true;
+        break;
+      }
+      if (s.lit_len) {
+        E.e_out[i] = (uint32_t)o;
+        E.e_src[i] = LW_LIT | s.lit_pos;
+        o += s.lit_len;
+        ++i;
+      }
+      if (s.mlen) {
+        E.e_out[i] = (uint32_t)o;
+        E.e_src[i] = s.offset;
+        o += s.mlen;
+        ++i;
+      }
+      q = s.next;
+    }
+    mine = i - first_elem;
+    end = q;
+    out_end = o;
+  }
+  // lanes behind one that stopped were entered for nothing
+  const uint64_t stops = __builtin_amdgcn_ballot_w64(stop);
+  if (stops && lane > (uint32_t)__builtin_ctzll(stops)) {
+    entry = LW_NONE;
+    mine = 0;
+  }
+  const uint64_t entered = __builtin_amdgcn_ballot_w64(entry != LW_NONE);
+  const uint32_t n = lw_uni((uint32_t)__builtin_amdgcn_readlane((int)wave_scan_inclusive(mine), 63));
+  const uint32_t last = entered ? lw_uni(63u - (uint32_t)__builtin_clzll(entered)) : 0u;
+  const uint32_t stream_end = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)last);
+  const uint32_t output_end = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)out_end, (int)last);  // (at most cap)
+  if (lane == 0) {
+    E.e_out[entered ? n : 0u] = entered ? output_end : op;
+    // (not entered cannot be: ip lies in the window)
+    const LwWindow w = {w0, staged, op, entered ? output_end : op, entered ? n : 0u, entered ? stream_end : ip, (!entered || stops != 0) ? 1u : 0u, 0u};
+    L.window(slot) = w;
+  }
+  LW_STAMP(3)
+}
+
+// The output of a parsed window, tile by tile, by XWAVES waves (this one is number xw of them); bar.sync() is their
+// barrier.  The tiles are in memory when it returns.
+template <uint32_t XWAVES, class LDS, class BAR>
+__device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t xw,
+                                           uint32_t lane, BAR& bar LW_PROF_ARGS) {
+  const LwWindow W = L.window(slot);
+  const uint8_t* win = L.win(slot);
+  const LwElems& E = L.elems(slot);
+  const uint32_t w0 = W.w0, staged = W.staged, n_elems = W.n_elems, o0 = W.o0, o1 = W.out_end;
+  const uint32_t xtid = xw * 64u + lane;
+  uint16_t* cell = L.cell();
+  uint32_t* start_bits = reinterpret_cast<uint32_t*>(L.cell());  // (a tile's first 512 bytes, before its cells are written)
   uint32_t round = 0;  // (counts the rounds of all tiles: the flag of a round is flag[round % 3]; a flag is cleared a round before its use)
+  uint32_t e_lo = 0;   // (the first wave's: elements below it start at or in front of the tile)
   for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
     const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
-    if (wave == 0) {
-      // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane; elements below e_lo start at
-      // or in front of the tile
-      uint32_t e_lo = L.e_lo;
-      cell[lane] = 0;
-      cell[lane + 64u] = 0;
+    if (xw == 0) {
+      // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane
+      start_bits[lane] = 0;
+      start_bits[lane + 64u] = 0;
       __builtin_amdgcn_wave_barrier();
       uint32_t dog3 = 0;
       for (;;) {
         LW_DOG(dog3, 3)
         const uint32_t i = e_lo + lane;
-        const bool in_front = i < n_elems && L.e_out[i] <= tb;
+        const bool in_front = i < n_elems && E.e_out[i] <= tb;
         const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
         e_lo += (uint32_t)__builtin_popcountll(m);
         if (m != ~0ull) break;
@@ -349,39 +431,37 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       for (uint32_t b = e_lo;; b += 64u) {
         LW_DOG(dog4, 4)
         const uint32_t i = b + lane;
-        const uint32_t eo = i < n_elems ? L.e_out[i] : 0xFFFFFFFFu;
+        const uint32_t eo = i < n_elems ? E.e_out[i] : 0xFFFFFFFFu;
         const bool inside = eo < te;
-        if (inside) atomicOr(&cell[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
+        if (inside) atomicOr(&start_bits[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
         if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
       }
       __builtin_amdgcn_wave_barrier();
-      const uint32_t lo = cell[2u * lane], hi = cell[2u * lane + 1u];
+      const uint32_t lo = start_bits[2u * lane], hi = start_bits[2u * lane + 1u];
       const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-      L.t_lo[lane] = lo;
-      L.t_hi[lane] = hi;
-      L.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
-      if (lane == 0) {
-        L.e_lo = e_lo;
-        L.flag[round % 3u] = 0;
-      }
+      L.t.t_lo[lane] = lo;
+      L.t.t_hi[lane] = hi;
+      L.t.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
+      if (lane == 0) L.t.flag[round % 3u] = 0;
     }
-    __syncthreads();
+    bar.sync();
     LW_STAMP(4)
     const uint32_t a = (uint32_t)((uintptr_t)(dst + tb) & 15u);
     const uint64_t upto = (2ull << lane) - 1ull;
     // a word per byte of the tile: LW_HAS | the byte, or the tile position of the byte it repeats
     const uint32_t n_steps = (te - tb + 63u) >> 6;
     bool open = false;
-    for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += WAVES * LW_UNROLL) {
-      uint32_t eo[LW_UNROLL], es[LW_UNROLL], word[LW_UNROLL];
+    for (uint32_t t0 = xw * LW_UNROLL; t0 < n_steps; t0 += XWAVES * LW_UNROLL) {
+      uint32_t eo[LW_UNROLL], es[LW_UNROLL];
+      uint16_t word[LW_UNROLL];
 #pragma unroll
       for (uint32_t u = 0; u < LW_UNROLL; ++u) {
         const uint32_t t = t0 + u < n_steps ? t0 + u : n_steps - 1u;
-        const uint64_t st = ((uint64_t)L.t_hi[t] << 32) | L.t_lo[t];
-        uint32_t i = L.t_before[t] + (uint32_t)__builtin_popcountll(st & upto);
+        const uint64_t st = ((uint64_t)L.t.t_hi[t] << 32) | L.t.t_lo[t];
+        uint32_t i = L.t.t_before[t] + (uint32_t)__builtin_popcountll(st & upto);
         i = i < n_elems ? i : n_elems - 1u;  // (bytes behind the output's end: any element, the result is not used)
-        eo[u] = L.e_out[i];
-        es[u] = L.e_src[i];
+        eo[u] = E.e_out[i];
+        es[u] = E.e_src[i];
       }
 #pragma unroll
       for (uint32_t u = 0; u < LW_UNROLL; ++u) {
@@ -391,14 +471,14 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
         if (t0 + u < n_steps && o < te) {
           if (es[u] & LW_LIT) {
             const uint32_t at = (es[u] & ~LW_LIT) + rel;
-            word[u] = LW_HAS | (at < staged ? (uint32_t)L.win[lw_at(at - w0)] : (uint32_t)src[at]);
+            word[u] = LW_HAS | (uint16_t)(at < staged ? win[lw_at(at - w0)] : src[at]);
           } else {
             uint32_t from = o - es[u];
             if (rel >= es[u]) from = eo[u] - es[u] + rel % es[u];  // a match that repeats itself: the first period
             if (from < tb) {
-              word[u] = LW_HAS | (uint32_t)LW_FAR_LOAD(dst + from);  // (written by this workgroup and waited for: read where the stores went)
+              word[u] = LW_HAS | (uint16_t)LW_FAR_LOAD(dst + from);  // (written by this workgroup and waited for: read where the stores went)
             } else {
-              word[u] = from - tb;
+              word[u] = (uint16_t)(from - tb);
               open = true;
             }
           }
@@ -408,20 +488,20 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       for (uint32_t u = 0; u < LW_UNROLL; ++u)
         if (t0 + u < n_steps) cell[(t0 + u) * 64u + lane] = word[u];
     }
-    if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.flag[round % 3u] = 1;
-    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.t.flag[round % 3u] = 1;
+    bar.sync();
     LW_STAMP(5)
     // every byte follows its pointer until it arrives at a byte that has its value
     uint32_t dog5 = 0;
-    while (L.flag[round % 3u]) {
+    while (L.t.flag[round % 3u] && !bar.aborted()) {
       LW_DOG(dog5, 5)
       ++round;
-      if (tid == 0) L.flag[(round + 1u) % 3u] = 0;  // (the flag of the round after this one: last read two rounds ago)
+      if (xtid == 0) L.t.flag[(round + 1u) % 3u] = 0;  // (the flag of the round after this one: last read two rounds ago)
       const bool was_open = open;
       open = false;
       if (__builtin_amdgcn_ballot_w64(was_open)) {
-        for (uint32_t t0 = wave * LW_UNROLL; t0 < n_steps; t0 += WAVES * LW_UNROLL) {
-          uint32_t mine_[LW_UNROLL], other[LW_UNROLL];
+        for (uint32_t t0 = xw * LW_UNROLL; t0 < n_steps; t0 += XWAVES * LW_UNROLL) {
+          uint16_t mine_[LW_UNROLL], other[LW_UNROLL];
 #pragma unroll
           for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
 #pragma unroll
@@ -435,8 +515,8 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
           }
         }
       }
-      if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.flag[round % 3u] = 1;
-      __syncthreads();
+      if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.t.flag[round % 3u] = 1;
+      bar.sync();
     }
     ++round;
     LW_STAMP(6)
@@ -444,7 +524,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
     {
       PQD_GLOBAL uint8_t* gbase = dst + tb - a;  // 16-byte aligned
       const uint32_t stop_at = a + (te - tb);
-      for (uint32_t t = tid * 16u; t < stop_at; t += WAVES * 1024u) {
+      for (uint32_t t = xtid * 16u; t < stop_at; t += XWAVES * 1024u) {
         // the bytes of tile positions t - a .. t - a + 15
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -463,12 +543,30 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is in memory when the next one reads from it
-    __syncthreads();
+    bar.sync();
     LW_STAMP(7)
   }
-  op = o1;
-  ip = new_ip;
-  return stopped;
+}
+
+// One window, parsed by the first wave and then executed by all WAVES waves of the workgroup: the sequences from
+// stream position ip on; ip / op move behind them.  Returns true when the chain stopped in front of a sequence that
+// the caller has to take by itself.
+template <int CODEC, uint32_t WAVES>
+__device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t& ip, uint32_t& op,
+                                          uint32_t in_end, uint32_t cap, uint32_t tid LW_PROF_ARGS) {
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  __syncthreads();
+  lw_stage(L.win(0), src, ip, lw_staged_end(ip, in_end), tid * 16u, WAVES * 1024u);
+  __syncthreads();
+  LW_STAMP(0)
+  if (wave == 0) lw_parse_window<CODEC>(L, 0u, ip, op, in_end, cap, lane LW_PROF_PASS);
+  __syncthreads();
+  LwAllWaves bar;
+  lw_execute<WAVES>(L, 0u, src, dst, wave, lane, bar LW_PROF_PASS);
+  const LwWindow W = L.window(0);  // (rewritten behind the next window's first barrier)
+  op = W.out_end;
+  ip = W.new_ip;
+  return W.stopped != 0u;
 }
 
 // ---- one sequence, wave-uniformly, with its bytes moved from memory to memory: the sequences the windows stop at
@@ -608,6 +706,24 @@ __device__ __forceinline__ bool lw_one(const PQD_GLOBAL uint8_t* src, PQD_GLOBAL
   return true;
 }
 
+// Snappy's preamble: the uncompressed length as a varint32.  false: it is broken (ip stays 0).
+__device__ __forceinline__ bool lw_snappy_preamble(const PQD_GLOBAL uint8_t* src, uint32_t in_end, uint32_t& ip, uint64_t& ulen) {
+  uint32_t shift = 0, at = 0;
+  ulen = 0;
+  while (at < in_end && shift <= 28u) {
+    const uint32_t b = lw_byte(src, at);
+    ++at;
+    ulen |= (uint64_t)(b & 0x7Fu) << shift;
+    if (!(b & 0x80u)) {
+      if (ulen > 0xFFFFFFFFull) return false;
+      ip = at;
+      return true;
+    }
+    shift += 7u;
+  }
+  return false;
+}
+
 template <int CODEC, uint32_t WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
                                                             pqd_page_result* __restrict__ results, uint32_t n_pages) {
@@ -630,25 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_de
   uint32_t ip = 0, op = 0;
   int32_t status = PQD_OK;
   uint64_t ulen = 0;
-  if (CODEC == PQD_CODEC_SNAPPY) {
-    // preamble: the uncompressed length as a varint32
-    uint32_t shift = 0;
-    bool ok = false;
-    while (ip < in_end && shift <= 28u) {
-      const uint32_t b = lw_byte(src, ip);
-      ++ip;
-      ulen |= (uint64_t)(b & 0x7Fu) << shift;
-      if (!(b & 0x80u)) {
-        ok = true;
-        break;
-      }
-      shift += 7u;
-    }
-    if (!ok || ulen > 0xFFFFFFFFull) {
-      status = PQD_DECODE;
-      ip = 0;
-    }
-  }
+  if (CODEC == PQD_CODEC_SNAPPY && !lw_snappy_preamble(src, in_end, ip, ulen)) status = PQD_DECODE;
 #ifdef LW_PROF
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t prof_t = __builtin_readcyclecounter();
@@ -664,15 +762,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_de
         const bool fine = lw_one<CODEC>(src, dst, ip, op, in_end, cap, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
-          L.new_ip = ip;
-          L.out_end = op;
-          L.stopped = !fine;
+          L.after_ip = ip;
+          L.after_op = op;
+          L.after_failed = fine ? 0u : 1u;
         }
       }
       __syncthreads();
-      ip = L.new_ip;
-      op = L.out_end;
-      const bool failed = L.stopped;
+      ip = L.after_ip;
+      op = L.after_op;
+      const bool failed = L.after_failed != 0u;
       __syncthreads();
       if (failed) {
         status = PQD_DECODE;
@@ -690,6 +788,111 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_de
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && cap >= 64u)
     for (int k = 0; k < 8; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
+#endif
+}
+
+// The same with the parse of a window and the execution of the window before it going on at once: the first wave
+// parses (and stages its window by itself), the other WAVES - 1 execute; the two meet at a workgroup barrier once per
+// window.  A sequence that has to be taken by itself waits until everything in front of it has been executed.
+template <int CODEC, uint32_t WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_lz_pipe_pages(const pqd_decompress_desc* __restrict__ descs,
+                                                                 pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  __shared__ LwPipeLds L;
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_decompress_desc d = descs[page];
+  if (d.codec != (uint32_t)CODEC) return;  // another kernel's page
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (d.src_len > 0x7fffffffu) {
+    if (tid == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.src;
+  PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)d.dst;
+  const uint32_t cap = d.dst_len, in_end = d.src_len;
+  uint32_t ip = 0, op = 0;
+  int32_t status = PQD_OK;
+  uint64_t ulen = 0;
+  if (CODEC == PQD_CODEC_SNAPPY && !lw_snappy_preamble(src, in_end, ip, ulen)) status = PQD_DECODE;
+#ifdef LW_PROF
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_readcyclecounter();
+#endif
+  if (tid == 0) {
+    L.arrived = 0;
+    L.abort = 0;
+  }
+  __syncthreads();
+  LwExecWaves bar = {&L.arrived, &L.abort, 0u, WAVES - 1u, lane};
+  bool parse_on = true;     // false: a window stopped in front of a sequence that is to be taken by itself
+  int exec_slot = -1;       // the parsed window that has not been executed yet
+  uint32_t parse_slot = 0;
+  uint32_t dog7 = 0;
+  while (status == PQD_OK) {
+    LW_DOG(dog7, 7)
+    const bool do_parse = parse_on && ip < in_end;
+    if (!do_parse && exec_slot < 0) {
+      if (parse_on || ip >= in_end) break;  // the stream is used up
+      // one sequence by the first wave (everything in front of it is in memory); the others learn where it ended
+      if (wave == 0) {
+        const bool fine = lw_one<CODEC>(src, dst, ip, op, in_end, cap, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          L.after_ip = ip;
+          L.after_op = op;
+          L.after_failed = fine ? 0u : 1u;
+        }
+      }
+      __syncthreads();
+      ip = L.after_ip;
+      op = L.after_op;
+      if (L.after_failed) status = PQD_DECODE;
+      __syncthreads();
+      parse_on = true;
+      continue;
+    }
+    if (wave == 0) {
+      if (do_parse) {
+        lw_stage(L.win(parse_slot), src, ip, lw_staged_end(ip, in_end), lane * 16u, 1024u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        LW_STAMP(0)
+        lw_parse_window<CODEC>(L, parse_slot, ip, op, in_end, cap, lane LW_PROF_PASS);
+      }
+    } else if (exec_slot >= 0) {
+      lw_execute<WAVES - 1u>(L, (uint32_t)exec_slot, src, dst, wave - 1u, lane, bar LW_PROF_PASS);
+    }
+    __syncthreads();
+    exec_slot = -1;
+    if (do_parse) {
+      const LwWindow W = L.window(parse_slot);
+      ip = W.new_ip;
+      op = W.out_end;
+      if (W.stopped) parse_on = false;
+      exec_slot = (int)parse_slot;
+      parse_slot ^= 1u;
+    }
+    if (L.abort) status = PQD_DECODE;
+  }
+  // the stream produces what its preamble announced (Snappy), and the page what its header announced
+  if (status == PQD_OK && ((CODEC == PQD_CODEC_SNAPPY && op != ulen) || op != cap)) status = PQD_DECODE;
+  if (tid == 0) {
+    pqd_page_result r = {status, op, ip, 0u};
+    results[page] = r;
+  }
+#ifdef LW_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (cap >= 64u) {
+    if (tid == 0)
+      for (int k = 0; k < 4; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
+    if (tid == 64u)
+      for (int k = 4; k < 8; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
+  }
 #endif
 }
 
@@ -723,25 +926,47 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
   }
 }
 
-template <uint32_t WAVES>
+template <uint32_t WAVES, bool PIPE>
 static void launch_lz_waves(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
-  if (codec == PQD_CODEC_SNAPPY)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
-  else if (codec == PQD_CODEC_LZ4_RAW)
-    hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+  if (codec == PQD_CODEC_SNAPPY) {
+    if (PIPE)
+      hipLaunchKernelGGL((k_lz_pipe_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+    else
+      hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+  } else if (codec == PQD_CODEC_LZ4_RAW) {
+    if (PIPE)
+      hipLaunchKernelGGL((k_lz_pipe_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+    else
+      hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+  }
 }
 
 static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
-  // PQD_LZ_WAVES = 4, 8 or 16 fixes the waves per page (testing)
+  // PQD_LZ_WAVES = 4, 8 or 16 fixes the waves per page, PQD_LZ_PIPE = 0 / 1 the kind of kernel (testing)
   const char* env = getenv("PQD_LZ_WAVES");
   const int forced = env ? atoi(env) : 0;
-  const uint32_t waves = forced == 4 || forced == 8 || forced == 16 ? (uint32_t)forced : n_pages <= LW_FEW_PAGES ? 16u : n_pages <= LW_SOME_PAGES ? 8u : 4u;
+  const char* penv = getenv("PQD_LZ_PIPE");
+  const bool pipe = penv ? atoi(penv) != 0 : n_pages <= LW_PIPE4_PAGES;
+  const uint32_t waves = forced == 4 || forced == 8 || forced == 16 ? (uint32_t)forced
+                         : !pipe                                   ? 4u
+                         : n_pages <= LW_PIPE16_PAGES              ? 16u
+                         : n_pages <= LW_PIPE8_PAGES               ? 8u
+                                                                   : 4u;
+  if (pipe) {
+    if (waves == 16u)
+      launch_lz_waves<16u, true>(descs, results, n_pages, codec, stream);
+    else if (waves == 8u)
+      launch_lz_waves<8u, true>(descs, results, n_pages, codec, stream);
+    else
+      launch_lz_waves<4u, true>(descs, results, n_pages, codec, stream);
+    return;
+  }
   if (waves == 16u)
-    launch_lz_waves<16u>(descs, results, n_pages, codec, stream);
+    launch_lz_waves<16u, false>(descs, results, n_pages, codec, stream);
   else if (waves == 8u)
-    launch_lz_waves<8u>(descs, results, n_pages, codec, stream);
+    launch_lz_waves<8u, false>(descs, results, n_pages, codec, stream);
   else
-    launch_lz_waves<4u>(descs, results, n_pages, codec, stream);
+    launch_lz_waves<4u, false>(descs, results, n_pages, codec, stream);
 }
 
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,

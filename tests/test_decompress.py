@@ -554,12 +554,14 @@ def test_gpu_lz4_stream_that_ends_with_a_lone_token(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("kernel", ["pipe4", "pipe8", "serial4", "serial16"])
 @pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
-def test_gpu_lz_pages_with_four_and_eight_waves(orc, monkeypatch, codec_name, waves):
-    """The Snappy / LZ4 kernel runs sixteen waves per page in calls of few pages (every test here), eight and four in
-    larger ones: the same streams with the number of waves fixed."""
-    monkeypatch.setenv("PQD_LZ_WAVES", waves)
+def test_gpu_lz_pages_with_other_kernels_and_waves(orc, monkeypatch, codec_name, kernel):
+    """Calls of few pages (every test here) take the Snappy / LZ4 kernel whose first wave parses a window while fifteen
+    others execute the one before it; larger calls take it with eight and four waves, the largest the kernel whose four
+    waves parse, then execute: the same streams with kernel and waves fixed."""
+    monkeypatch.setenv("PQD_LZ_PIPE", "1" if kernel.startswith("pipe") else "0")
+    monkeypatch.setenv("PQD_LZ_WAVES", kernel.lstrip("pipeserial"))
     test_gpu_decompresses_library_streams_and_pages(orc, codec_name)
     test_gpu_damaged_streams(orc, codec_name)
     if codec_name == "LZ4_RAW":
