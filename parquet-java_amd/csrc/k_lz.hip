@@ -89,7 +89,6 @@ struct LwElems {
 struct LwTiles {
   uint32_t t_lo[64], t_hi[64];  // per 64 bytes of the tile: the bytes at which an element starts
   uint32_t t_before[64];        // the element that holds the byte in front of those 64
-  uint32_t flag[3];
 };
 
 // One window at a time, parsed and then executed by the same waves (22.5 KB: seven pages a CU; the table of places is
@@ -136,6 +135,7 @@ struct LwPipeLds {
 struct LwAllWaves {
   __device__ __forceinline__ void sync() { __syncthreads(); }
   __device__ __forceinline__ bool aborted() const { return false; }
+  __device__ __forceinline__ void give_up() {}
 };
 // All waves but the parsing one execute: every wave adds one to a counter in LDS and waits until all have (the counter
 // only grows; the comparison survives its wrap).  The waves of a workgroup are resident together, so the wait ends; a
@@ -160,6 +160,7 @@ struct LwExecWaves {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   __device__ __forceinline__ bool aborted() const { return __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; }
+  __device__ __forceinline__ void give_up() { __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };
 
 #ifdef LW_PROF
@@ -409,7 +410,6 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
   const uint32_t xtid = xw * 64u + lane;
   uint16_t* cell = L.cell();
   uint32_t* start_bits = reinterpret_cast<uint32_t*>(L.cell());  // (a tile's first 512 bytes, before its cells are written)
-  uint32_t round = 0;  // (counts the rounds of all tiles: the flag of a round is flag[round % 3]; a flag is cleared a round before its use)
   uint32_t e_lo = 0;   // (the first wave's: elements below it start at or in front of the tile)
   for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
     const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
@@ -442,7 +442,6 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
       L.t.t_lo[lane] = lo;
       L.t.t_hi[lane] = hi;
       L.t.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
-      if (lane == 0) L.t.flag[round % 3u] = 0;
     }
     bar.sync();
     LW_STAMP(4)
@@ -488,18 +487,17 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
       for (uint32_t u = 0; u < LW_UNROLL; ++u)
         if (t0 + u < n_steps) cell[(t0 + u) * 64u + lane] = word[u];
     }
-    if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.t.flag[round % 3u] = 1;
     bar.sync();
     LW_STAMP(5)
-    // every byte follows its pointer until it arrives at a byte that has its value
-    uint32_t dog5 = 0;
-    while (L.t.flag[round % 3u] && !bar.aborted()) {
-      LW_DOG(dog5, 5)
-      ++round;
-      if (xtid == 0) L.t.flag[(round + 1u) % 3u] = 0;  // (the flag of the round after this one: last read two rounds ago)
-      const bool was_open = open;
-      open = false;
-      if (__builtin_amdgcn_ballot_w64(was_open)) {
+    // Every byte follows its pointer until it arrives at a byte that has its value.  The waves do not wait for each
+    // other between rounds: whatever a cell holds at any time stands for its byte (a pointer to an equal byte further
+    // to the front, or the value), and pointers only lead to the front, where the cells get done first.
+    if (__builtin_amdgcn_ballot_w64(open)) {
+      uint32_t dog5 = 0, rounds = 0;
+      for (;;) {
+        LW_DOG(dog5, 5)
+        asm volatile("" ::: "memory");  // (the cells are read again: other waves write them)
+        open = false;
         for (uint32_t t0 = xw * LW_UNROLL; t0 < n_steps; t0 += XWAVES * LW_UNROLL) {
           uint16_t mine_[LW_UNROLL], other[LW_UNROLL];
 #pragma unroll
@@ -514,11 +512,14 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
             }
           }
         }
+        if (!__builtin_amdgcn_ballot_w64(open) || bar.aborted()) break;
+        if (++rounds > LW_PATIENCE) {  // (cannot be: every round brings the frontmost open cell to its value)
+          bar.give_up();
+          break;
+        }
       }
-      if (__builtin_amdgcn_ballot_w64(open) && lane == 0) L.t.flag[round % 3u] = 1;
-      bar.sync();
     }
-    ++round;
+    bar.sync();
     LW_STAMP(6)
     // tile -> memory: whole aligned 16-byte pieces, the ragged ends byte by byte
     {
