@@ -60,12 +60,14 @@ constexpr uint16_t LW_HAS = 0x8000u;  // a tile cell that holds its byte
 #ifndef LW_UNROLL
 #define LW_UNROLL 4u
 #endif
-// Kernel and waves per page by the size of the call.  A page's time is its two serial chains (the parse: one wave; the
-// pointer rounds of its tiles), not the CU's throughput: calls of at most 768 pages let the first wave parse the next
-// window while the others execute the one before (k_lz_pipe_pages; 52 KB of LDS: three pages a CU) with 16 / 8 / 4
-// waves in calls of at most 256 / 512 / 768 pages; larger ones take four waves that parse, then execute (22.5 KB: up
-// to seven pages a CU).  1 MiB pages of text, Snappy / LZ4: 256 pages 61 / 52 GB/s (one after the other: 45 / 33),
-// 512 pages 89 / 86 (68 / 56), 768 pages 95 / 95 (82 / 70), 1280 pages 115 / 100.
+// Kernel and waves per page by the size of the call.  A page's time is that of its serial chains (the parse: table,
+// chain, elements; the steps of its tiles) rather than the CU's throughput, so few pages get many waves each:
+//   at most 512 pages: k_lz_staged_pages, a wave for each of the parse's three steps and 13 (at most 256 pages) or 5
+//                      for the execution, all at once on four successive windows (77 KB of LDS: two pages a CU);
+//   at most 768 pages: k_lz_pipe_pages, one wave parses while three execute the window before (52 KB: three pages a CU);
+//   more:              k_lz_pages, four waves that parse, then execute (22.5 KB, 72 VGPRs: seven pages a CU).
+// 1 MiB pages of text / small integers / doubles, Snappy: 256 pages 82 / 76 / 70 GB/s (k_lz_pages with 16 waves: 45 /
+// 29 / 36), 512 pages 97 / 108 / 101, 768 pages 108 / 95 / 115, 1792 pages 154 / 135 / 157; LZ4 about a tenth less.
 constexpr uint32_t LW_PIPE16_PAGES = 256, LW_PIPE8_PAGES = 512, LW_PIPE4_PAGES = 768;
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -78,7 +80,8 @@ struct LwWindow {
   uint32_t w0, staged;    // the stream bytes in LDS: [w0, staged)
   uint32_t o0, out_end;   // the output of the window's elements: [o0, out_end)
   uint32_t n_elems, new_ip;
-  uint32_t stopped, pad;  // stopped: the chain ended in front of a sequence that is taken by itself
+  uint32_t stopped;       // the chain ended in front of a sequence that is taken by itself
+  uint32_t win_slot;      // where the window's bytes lie
 };
 
 struct LwElems {
@@ -107,6 +110,8 @@ struct LwLds {
   LwTiles t;
   LwWindow w_;
   uint32_t after_ip, after_op, after_failed;  // where a sequence taken by itself ended
+  // (a tile's first 512 bytes, before its cells are written)
+  __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(u.x.cell); }
   __device__ __forceinline__ uint8_t* win(uint32_t) { return win_; }
   __device__ __forceinline__ u32x2* place() { return u.place; }
   __device__ __forceinline__ LwElems& elems(uint32_t) { return u.x.e; }
@@ -121,11 +126,44 @@ struct LwPipeLds {
   LwElems e_[2];
   __attribute__((aligned(16))) uint16_t cell_[LW_TILE];
   LwTiles t;
+  // (a tile's first 512 bytes, before its cells are written)
+  __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(cell_); }
   LwWindow w_[2];
   uint32_t after_ip, after_op, after_failed;
   uint32_t arrived, abort;  // the executing waves' barrier: arrivals so far; a wait that ran out of patience
   __device__ __forceinline__ uint8_t* win(uint32_t s) { return win_[s]; }
   __device__ __forceinline__ u32x2* place() { return place_; }
+  __device__ __forceinline__ LwElems& elems(uint32_t s) { return e_[s]; }
+  __device__ __forceinline__ uint16_t* cell() { return cell_; }
+  __device__ __forceinline__ LwWindow& window(uint32_t s) { return w_[s]; }
+};
+
+// What the chaining wave hands to the one that lists the elements.
+struct LwChainRecord {
+  uint32_t entry[64], first_elem[64], first_out[64];
+  uint32_t w0, win_slot, ip, op;  // the window, and where the chain entered it
+  uint32_t next_ip, next_op;      // where the chain left it
+};
+
+// Four windows in flight, a wave for each of the parse's three serial steps: the first makes the table of places of a
+// window (windows then start at multiples of LW_WIN, so that a table does not depend on where the chain enters it),
+// the second follows the chain through the window before it, the third lists the elements of the one before that, the
+// others execute the one before that (76 KB: two pages a CU).
+struct LwStagedLds {
+  __attribute__((aligned(16))) uint8_t win_[4][LW_WIN + LW_SLACK + 32];
+  u32x2 place_[2][64 * 33];
+  LwChainRecord k_[2];
+  LwElems e_[2];
+  __attribute__((aligned(16))) uint16_t cell_[LW_TILE];
+  LwTiles t;
+  // (a tile's first 512 bytes, before its cells are written)
+  __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(cell_); }
+  LwWindow w_[2];
+  uint32_t after_ip, after_op, after_failed;
+  uint32_t arrived, abort;
+  __device__ __forceinline__ uint8_t* win(uint32_t s) { return win_[s]; }
+  __device__ __forceinline__ u32x2* place(uint32_t s) { return place_[s]; }
+  __device__ __forceinline__ LwChainRecord& chain(uint32_t s) { return k_[s]; }
   __device__ __forceinline__ LwElems& elems(uint32_t s) { return e_[s]; }
   __device__ __forceinline__ uint16_t* cell() { return cell_; }
   __device__ __forceinline__ LwWindow& window(uint32_t s) { return w_[s]; }
@@ -165,10 +203,12 @@ struct LwExecWaves {
 
 #ifdef LW_PROF
 #define LW_STAMP(k) { const uint64_t now_ = __builtin_readcyclecounter(); prof[k] += now_ - prof_t; prof_t = now_; }
+#define LW_TICK prof_t = __builtin_readcyclecounter();
 #define LW_PROF_ARGS , uint64_t* prof, uint64_t& prof_t
 #define LW_PROF_PASS , prof, prof_t
 #else
 #define LW_STAMP(k)
+#define LW_TICK
 #define LW_PROF_ARGS
 #define LW_PROF_PASS
 #endif
@@ -279,18 +319,12 @@ __device__ __forceinline__ uint32_t lw_staged_end(uint32_t w0, uint32_t in_end) 
   return in_end - w0 < LW_WIN + LW_SLACK ? in_end : w0 + LW_WIN + LW_SLACK;
 }
 
-// The parse of one window, by one wave: the sequences from stream position ip on (output position op), as far as the
-// window (or the chain of well-formed sequences) goes, become the slot's list of elements and its LwWindow record.
-// The window's bytes lie in L.win(slot).
-template <int CODEC, class LDS>
-__device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap,
-                                                uint32_t lane LW_PROF_ARGS) {
-  const uint32_t w0 = ip, staged = lw_staged_end(w0, in_end);
-  const uint8_t* win = L.win(slot);
-  u32x2* place = L.place();
-  LwElems& E = L.elems(slot);
-  // ---- 1. the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither
-  // of the two continues at the other; the one exception is dealt with below)
+// The table of places of the window that starts at stream position w0 (its bytes lie in `win`), by one wave:
+// the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither of the
+// two continues at the other; the one exception is dealt with below).
+template <int CODEC>
+__device__ __forceinline__ void lw_places(const uint8_t* win, u32x2* place, uint32_t w0, uint32_t in_end, uint32_t lane) {
+  const uint32_t staged = lw_staged_end(w0, in_end);
   const uint32_t seg = w0 + lane * 32u;
   for (int pl = 31; pl >= 1; pl -= 2) {
     LwSeq s[2];
@@ -319,39 +353,59 @@ __device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t 
     }
   }
   __builtin_amdgcn_wave_barrier();
-  LW_STAMP(1)
-  // ---- 2. the chain through the window
-  uint32_t entry = LW_NONE, first_elem = 0;
-  uint64_t first_out = 0;
-  {
-    uint32_t at = ip, elems = 0;
-    uint64_t made = op;
-    uint32_t dog1 = 0;
-    while (at < w0 + LW_WIN && at < in_end && made <= cap) {
-      LW_DOG(dog1, 1)
-      const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
-      const u32x2 e = place[k * 33u + pl];
-      const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
-      if (lane == k) {
-        entry = at;
-        first_elem = elems;
-        first_out = made;
-      }
-      elems += m >> 24;
-      made += m & 0xFFFFFFu;
-      if (ex & LW_FAIL) break;
-      at = ex;
+}
+
+// What the chain through a window leaves for a lane: where it enters the lane's segment (LW_NONE: it does not), and
+// how many elements and output bytes lie in front of that place.
+struct LwChained {
+  uint32_t entry, first_elem, first_out;
+};
+
+// The chain of sequences through a window whose table of places is made, by one wave: from stream position ip on
+// (output position op; ip lies in the window) as far as the window, or the chain of well-formed sequences, goes.
+// next_ip / next_op: where it leaves the window (what counts is where the listing of the elements ends: the two agree
+// unless that stops in front of a sequence, or the stream ends in the window).
+__device__ __forceinline__ LwChained lw_chain(const u32x2* place, uint32_t w0, uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap,
+                                              uint32_t lane, uint32_t& next_ip, uint32_t& next_op) {
+  LwChained c = {LW_NONE, 0u, 0u};
+  uint32_t at = ip, elems = 0;
+  uint64_t made = op;
+  uint32_t dog1 = 0;
+  while (at < w0 + LW_WIN && at < in_end && made <= cap) {
+    LW_DOG(dog1, 1)
+    const uint32_t k = (at - w0) >> 5, pl = (at - w0) & 31u;
+    const u32x2 e = place[k * 33u + pl];
+    const uint32_t ex = lw_uni(e.x), m = lw_uni(e.y);
+    if (lane == k) {
+      c.entry = at;
+      c.first_elem = elems;
+      c.first_out = (uint32_t)made;  // (at most cap)
     }
+    elems += m >> 24;
+    made += m & 0xFFFFFFu;
+    if (ex & LW_FAIL) break;
+    at = ex;
   }
-  __builtin_amdgcn_wave_barrier();  // (where the list below takes the table's room)
-  LW_STAMP(2)
-  // ---- 3. this lane's elements
+  next_ip = at;
+  next_op = (uint32_t)made;
+  return c;
+}
+
+// The elements of a chained window, by one wave: every lane that the chain entered walks its segment forward and
+// writes its elements into the list E; the record *out says where the list ends.  A sequence that breaks a rule or
+// needs bytes that are not staged ends the list in front of it (out->stopped).
+template <int CODEC>
+__device__ __forceinline__ void lw_elements(const uint8_t* win, LwChained c, LwElems& E, LwWindow* out, uint32_t win_slot, uint32_t w0,
+                                            uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap, uint32_t lane) {
+  const uint32_t staged = lw_staged_end(w0, in_end);
+  const uint32_t seg = w0 + lane * 32u;
+  uint32_t entry = c.entry;
   uint32_t mine = 0, end = 0;
   uint64_t out_end = 0;
   bool stop = false;
   if (entry != LW_NONE) {
-    uint32_t q = entry, i = first_elem;
-    uint64_t o = first_out;
+    uint32_t q = entry, i = c.first_elem;
+    uint64_t o = c.first_out;
     uint32_t dog2 = 0;
     while (q < seg + 32u && q < in_end) {
       LW_DOG(dog2, 2)
@@ -374,7 +428,7 @@ __device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t 
       }
       q = s.next;
     }
-    mine = i - first_elem;
+    mine = i - c.first_elem;
     end = q;
     out_end = o;
   }
@@ -392,10 +446,32 @@ __device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t 
   if (lane == 0) {
     E.e_out[entered ? n : 0u] = entered ? output_end : op;
     // (not entered cannot be: ip lies in the window)
-    const LwWindow w = {w0, staged, op, entered ? output_end : op, entered ? n : 0u, entered ? stream_end : ip, (!entered || stops != 0) ? 1u : 0u, 0u};
-    L.window(slot) = w;
+    const LwWindow w = {w0, staged, op, entered ? output_end : op, entered ? n : 0u, entered ? stream_end : ip, (!entered || stops != 0) ? 1u : 0u, win_slot};
+    *out = w;
   }
+}
+
+// Both by the same wave.
+template <int CODEC>
+__device__ __forceinline__ void lw_chain_elements(const uint8_t* win, const u32x2* place, LwElems& E, LwWindow* out, uint32_t win_slot,
+                                                  uint32_t w0, uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap,
+                                                  uint32_t lane LW_PROF_ARGS) {
+  uint32_t next_ip, next_op;
+  const LwChained c = lw_chain(place, w0, ip, op, in_end, cap, lane, next_ip, next_op);
+  asm volatile("" ::: "memory");  // (where the list takes the table's room: no look-up moves behind this line)
+  __builtin_amdgcn_wave_barrier();
+  LW_STAMP(2)
+  lw_elements<CODEC>(win, c, E, out, win_slot, w0, ip, op, in_end, cap, lane);
   LW_STAMP(3)
+}
+
+// The parse of the window that starts at ip, by one wave: table, chain and elements.  The window's bytes lie in L.win(slot).
+template <int CODEC, class LDS>
+__device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t ip, uint32_t op, uint32_t in_end, uint32_t cap,
+                                                uint32_t lane LW_PROF_ARGS) {
+  lw_places<CODEC>(L.win(slot), L.place(), ip, in_end, lane);
+  LW_STAMP(1)
+  lw_chain_elements<CODEC>(L.win(slot), L.place(), L.elems(slot), &L.window(slot), slot, ip, ip, op, in_end, cap, lane LW_PROF_PASS);
 }
 
 // The output of a parsed window, tile by tile, by XWAVES waves (this one is number xw of them); bar.sync() is their
@@ -403,46 +479,52 @@ __device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t 
 template <uint32_t XWAVES, class LDS, class BAR>
 __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t xw,
                                            uint32_t lane, BAR& bar LW_PROF_ARGS) {
+  constexpr uint32_t NW = XWAVES;  // waves that share the bytes of a tile
+  // steps of 64 bytes a wave takes at a time: the 64 steps of a tile are shared out evenly
+  constexpr uint32_t UN = NW >= 16u ? 4u : NW >= 13u ? 5u : NW >= 11u ? 6u : LW_UNROLL;
   const LwWindow W = L.window(slot);
-  const uint8_t* win = L.win(slot);
+  const uint8_t* win = L.win(W.win_slot);
   const LwElems& E = L.elems(slot);
   const uint32_t w0 = W.w0, staged = W.staged, n_elems = W.n_elems, o0 = W.o0, o1 = W.out_end;
   const uint32_t xtid = xw * 64u + lane;
   uint16_t* cell = L.cell();
-  uint32_t* start_bits = reinterpret_cast<uint32_t*>(L.cell());  // (a tile's first 512 bytes, before its cells are written)
-  uint32_t e_lo = 0;   // (the first wave's: elements below it start at or in front of the tile)
+  uint32_t* start_bits = L.bits();
+  uint32_t e_lo = 0;  // (the first wave's: elements below it start at or in front of the tile)
+  // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane
+  auto masks = [&](uint32_t tb, LwTiles& T) {
+    const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
+    start_bits[lane] = 0;
+    start_bits[lane + 64u] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t dog3 = 0;
+    for (;;) {
+      LW_DOG(dog3, 3)
+      const uint32_t i = e_lo + lane;
+      const bool in_front = i < n_elems && E.e_out[i] <= tb;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
+      e_lo += (uint32_t)__builtin_popcountll(m);
+      if (m != ~0ull) break;
+    }
+    uint32_t dog4 = 0;
+    for (uint32_t b = e_lo;; b += 64u) {
+      LW_DOG(dog4, 4)
+      const uint32_t i = b + lane;
+      const uint32_t eo = i < n_elems ? E.e_out[i] : 0xFFFFFFFFu;
+      const bool inside = eo < te;
+      if (inside) atomicOr(&start_bits[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
+      if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t lo = start_bits[2u * lane], hi = start_bits[2u * lane + 1u];
+    const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
+    T.t_lo[lane] = lo;
+    T.t_hi[lane] = hi;
+    T.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
+  };
   for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
     const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
-    if (xw == 0) {
-      // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane
-      start_bits[lane] = 0;
-      start_bits[lane + 64u] = 0;
-      __builtin_amdgcn_wave_barrier();
-      uint32_t dog3 = 0;
-      for (;;) {
-        LW_DOG(dog3, 3)
-        const uint32_t i = e_lo + lane;
-        const bool in_front = i < n_elems && E.e_out[i] <= tb;
-        const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
-        e_lo += (uint32_t)__builtin_popcountll(m);
-        if (m != ~0ull) break;
-      }
-      uint32_t dog4 = 0;
-      for (uint32_t b = e_lo;; b += 64u) {
-        LW_DOG(dog4, 4)
-        const uint32_t i = b + lane;
-        const uint32_t eo = i < n_elems ? E.e_out[i] : 0xFFFFFFFFu;
-        const bool inside = eo < te;
-        if (inside) atomicOr(&start_bits[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
-        if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t lo = start_bits[2u * lane], hi = start_bits[2u * lane + 1u];
-      const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-      L.t.t_lo[lane] = lo;
-      L.t.t_hi[lane] = hi;
-      L.t.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
-    }
+    const LwTiles& T = L.t;
+    if (xw == 0) masks(tb, L.t);
     bar.sync();
     LW_STAMP(4)
     const uint32_t a = (uint32_t)((uintptr_t)(dst + tb) & 15u);
@@ -450,20 +532,20 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
     // a word per byte of the tile: LW_HAS | the byte, or the tile position of the byte it repeats
     const uint32_t n_steps = (te - tb + 63u) >> 6;
     bool open = false;
-    for (uint32_t t0 = xw * LW_UNROLL; t0 < n_steps; t0 += XWAVES * LW_UNROLL) {
-      uint32_t eo[LW_UNROLL], es[LW_UNROLL];
-      uint16_t word[LW_UNROLL];
+    for (uint32_t t0 = xw * UN; t0 < n_steps; t0 += NW * UN) {
+      uint32_t eo[UN], es[UN];
+      uint16_t word[UN];
 #pragma unroll
-      for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+      for (uint32_t u = 0; u < UN; ++u) {
         const uint32_t t = t0 + u < n_steps ? t0 + u : n_steps - 1u;
-        const uint64_t st = ((uint64_t)L.t.t_hi[t] << 32) | L.t.t_lo[t];
-        uint32_t i = L.t.t_before[t] + (uint32_t)__builtin_popcountll(st & upto);
+        const uint64_t st = ((uint64_t)T.t_hi[t] << 32) | T.t_lo[t];
+        uint32_t i = T.t_before[t] + (uint32_t)__builtin_popcountll(st & upto);
         i = i < n_elems ? i : n_elems - 1u;  // (bytes behind the output's end: any element, the result is not used)
         eo[u] = E.e_out[i];
         es[u] = E.e_src[i];
       }
 #pragma unroll
-      for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+      for (uint32_t u = 0; u < UN; ++u) {
         const uint32_t o = tb + (t0 + u) * 64u + lane;
         const uint32_t rel = o - eo[u];
         word[u] = LW_HAS;
@@ -484,7 +566,7 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
         }
       }
 #pragma unroll
-      for (uint32_t u = 0; u < LW_UNROLL; ++u)
+      for (uint32_t u = 0; u < UN; ++u)
         if (t0 + u < n_steps) cell[(t0 + u) * 64u + lane] = word[u];
     }
     bar.sync();
@@ -498,20 +580,23 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
         LW_DOG(dog5, 5)
         asm volatile("" ::: "memory");  // (the cells are read again: other waves write them)
         open = false;
-        for (uint32_t t0 = xw * LW_UNROLL; t0 < n_steps; t0 += XWAVES * LW_UNROLL) {
-          uint16_t mine_[LW_UNROLL], other[LW_UNROLL];
+        for (uint32_t t0 = xw * UN; t0 < n_steps; t0 += NW * UN) {
+          uint16_t mine_[UN], other[UN];
 #pragma unroll
-          for (uint32_t u = 0; u < LW_UNROLL; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
+          for (uint32_t u = 0; u < UN; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
 #pragma unroll
-          for (uint32_t u = 0; u < LW_UNROLL; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
+          for (uint32_t u = 0; u < UN; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
 #pragma unroll
-          for (uint32_t u = 0; u < LW_UNROLL; ++u) {
+          for (uint32_t u = 0; u < UN; ++u) {
             if (!(mine_[u] & LW_HAS)) {
               cell[(t0 + u) * 64u + lane] = other[u];  // its value, or the byte that one repeats
               open = open || !(other[u] & LW_HAS);
             }
           }
         }
+#ifdef LW_COUNT_ROUNDS
+        prof[7] += 1000;
+#endif
         if (!__builtin_amdgcn_ballot_w64(open) || bar.aborted()) break;
         if (++rounds > LW_PATIENCE) {  // (cannot be: every round brings the frontmost open cell to its value)
           bar.give_up();
@@ -525,7 +610,7 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
     {
       PQD_GLOBAL uint8_t* gbase = dst + tb - a;  // 16-byte aligned
       const uint32_t stop_at = a + (te - tb);
-      for (uint32_t t = xtid * 16u; t < stop_at; t += XWAVES * 1024u) {
+      for (uint32_t t = xtid * 16u; t < stop_at; t += NW * 1024u) {
         // the bytes of tile positions t - a .. t - a + 15
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -545,7 +630,9 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile is in memory when the next one reads from it
     bar.sync();
+#ifndef LW_COUNT_ROUNDS
     LW_STAMP(7)
+#endif
   }
 }
 
@@ -897,6 +984,187 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pipe_pages(const pqd_decompre
 #endif
 }
 
+// The same with the three serial steps of the parse and the execution going on at once, each on the window behind
+// the next step's: table (first wave), chain (second), elements (third), execution (the other WAVES - 3); a workgroup
+// barrier once per window.  The chain may leave a window far behind the next one (a long literal): the table made
+// meanwhile is then of no use, and the next one is made where the chain arrived.  The chain runs ahead of the check of
+// the sequences it passes (the listing of the elements): when that stops in front of a sequence, what was chained
+// behind it does not count.
+template <int CODEC, uint32_t WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decompress_desc* __restrict__ descs,
+                                                                   pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lw_staged_lds[];
+  LwStagedLds& L = *reinterpret_cast<LwStagedLds*>(lw_staged_lds);
+  const uint32_t page = blockIdx.x;
+  if (page >= n_pages) return;
+  const pqd_decompress_desc d = descs[page];
+  if (d.codec != (uint32_t)CODEC) return;  // another kernel's page
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (d.src_len > 0x7fffffffu) {
+    if (tid == 0) {
+      pqd_page_result r = {PQD_BAD_ARG, 0u, 0u, 0u};
+      results[page] = r;
+    }
+    return;
+  }
+  const PQD_GLOBAL uint8_t* src = (const PQD_GLOBAL uint8_t*)d.src;
+  PQD_GLOBAL uint8_t* dst = (PQD_GLOBAL uint8_t*)d.dst;
+  const uint32_t cap = d.dst_len, in_end = d.src_len;
+  uint32_t ip = 0, op = 0;  // behind the last window whose elements are listed
+  int32_t status = PQD_OK;
+  uint64_t ulen = 0;
+  if (CODEC == PQD_CODEC_SNAPPY && !lw_snappy_preamble(src, in_end, ip, ulen)) status = PQD_DECODE;
+#ifdef LW_PROF
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof_t = __builtin_readcyclecounter();
+#endif
+  if (tid == 0) {
+    L.arrived = 0;
+    L.abort = 0;
+  }
+  __syncthreads();
+  LwExecWaves bar = {&L.arrived, &L.abort, 0u, WAVES - 3u, lane};
+  uint32_t cip = ip, cop = op;  // where the chain has arrived
+  bool parse_on = true;     // false: a window stopped in front of a sequence that is to be taken by itself
+  bool tab_valid = false;   // a table is made and not used yet: that of window tab_grid, the tab_seq-th made
+  uint32_t tab_grid = 0, tab_seq = 0;
+  bool chain_valid = false;  // a window is chained and its elements are not listed yet
+  uint32_t a_seq = 0, b_seq = 0, c_seq = 0;  // tables made, windows chained, windows listed
+  int x_slot = -1;          // the listed window that has not been executed yet
+  uint32_t dog7 = 0;
+  while (status == PQD_OK) {
+    LW_DOG(dog7, 7)
+    const bool more = parse_on && cip < in_end;
+    const uint32_t grid = cip / LW_WIN;
+    const bool b_work = more && tab_valid && tab_grid == grid;
+    // the table to make: of the window behind the one that is being chained, or of the one the chain has arrived in
+    const uint32_t a_grid = b_work ? tab_grid + 1u : grid;
+    const bool a_work = more && a_grid * LW_WIN < in_end;
+    const bool c_work = chain_valid;
+    if (!a_work && !b_work && !c_work && x_slot < 0) {
+      if (parse_on || ip >= in_end) break;  // the stream is used up
+      // one sequence by the first wave (everything in front of it is in memory); the others learn where it ended
+      if (wave == 0) {
+        const bool fine = lw_one<CODEC>(src, dst, ip, op, in_end, cap, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          L.after_ip = ip;
+          L.after_op = op;
+          L.after_failed = fine ? 0u : 1u;
+        }
+      }
+      __syncthreads();
+      ip = L.after_ip;
+      op = L.after_op;
+      if (L.after_failed) status = PQD_DECODE;
+      __syncthreads();
+      cip = ip;
+      cop = op;
+      parse_on = true;
+      continue;
+    }
+    if (wave == 0) {
+      if (a_work) {
+        LW_TICK
+        const uint32_t w0 = a_grid * LW_WIN;
+        uint8_t* win = L.win(a_seq & 3u);
+        lw_stage(win, src, w0, lw_staged_end(w0, in_end), lane * 16u, 1024u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        LW_STAMP(0)
+        lw_places<CODEC>(win, L.place(a_seq & 1u), w0, in_end, lane);
+        LW_STAMP(1)
+      }
+    } else if (wave == 1) {
+      if (b_work) {
+        LW_TICK
+        LwChainRecord& K = L.chain(b_seq & 1u);
+        uint32_t next_ip, next_op;
+        const LwChained c = lw_chain(L.place(tab_seq & 1u), tab_grid * LW_WIN, cip, cop, in_end, cap, lane, next_ip, next_op);
+        K.entry[lane] = c.entry;
+        K.first_elem[lane] = c.first_elem;
+        K.first_out[lane] = c.first_out;
+        if (lane == 0) {
+          K.w0 = tab_grid * LW_WIN;
+          K.win_slot = tab_seq & 3u;
+          K.ip = cip;
+          K.op = cop;
+          K.next_ip = next_ip;
+          K.next_op = next_op;
+        }
+        LW_STAMP(2)
+      }
+    } else if (wave == 2) {
+      if (c_work) {
+        LW_TICK
+        const LwChainRecord& K = L.chain((b_seq - 1u) & 1u);
+        const LwChained c = {K.entry[lane], K.first_elem[lane], K.first_out[lane]};
+        lw_elements<CODEC>(L.win(K.win_slot), c, L.elems(c_seq & 1u), &L.window(c_seq & 1u), K.win_slot, K.w0, K.ip, K.op, in_end, cap, lane);
+        LW_STAMP(3)
+      }
+    } else if (x_slot >= 0) {
+      LW_TICK
+      lw_execute<WAVES - 3u>(L, (uint32_t)x_slot, src, dst, wave - 3u, lane, bar LW_PROF_PASS);
+    }
+    __syncthreads();
+    x_slot = -1;
+    bool stopped = false, astray = false;
+    if (c_work) {
+      const LwWindow W = L.window(c_seq & 1u);
+      ip = W.new_ip;
+      op = W.out_end;
+      stopped = W.stopped != 0u;
+      // (at the stream's end the chain does not say where it left: the place behind the last sequence is none)
+      const LwChainRecord& KC = L.chain((b_seq - 1u) & 1u);
+      astray = W.new_ip != KC.next_ip || W.out_end != KC.next_op;
+      x_slot = (int)(c_seq & 1u);
+      ++c_seq;
+      chain_valid = false;
+    }
+    if (b_work) {
+      const LwChainRecord& K = L.chain(b_seq & 1u);
+      cip = K.next_ip;
+      cop = K.next_op;
+      chain_valid = true;
+      ++b_seq;
+      tab_valid = false;
+    }
+    if (a_work) {
+      tab_valid = true;
+      tab_grid = a_grid;
+      tab_seq = a_seq;
+      ++a_seq;
+    }
+    if (stopped || astray) {  // what was chained and tabled behind the stop does not count
+      if (stopped) parse_on = false;
+      chain_valid = false;
+      tab_valid = false;
+      cip = ip;
+      cop = op;
+    }
+    if (L.abort) status = PQD_DECODE;
+  }
+  // the stream produces what its preamble announced (Snappy), and the page what its header announced
+  if (status == PQD_OK && ((CODEC == PQD_CODEC_SNAPPY && op != ulen) || op != cap)) status = PQD_DECODE;
+  if (tid == 0) {
+    pqd_page_result r = {status, op, ip, 0u};
+    results[page] = r;
+  }
+#ifdef LW_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (cap >= 64u) {
+    if (tid == 0)
+      for (int k = 0; k < 2; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
+    if (tid == 64u) ((PQD_GLOBAL uint64_t*)d.dst)[2] = prof[2];
+    if (tid == 128u) ((PQD_GLOBAL uint64_t*)d.dst)[3] = prof[3];
+    if (tid == 192u)
+      for (int k = 4; k < 8; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
+  }
+#endif
+}
+
 // stored bytes (an uncompressed codec, the level bytes of a V2 page, a V2 page with is_compressed = false)
 // A descriptor whose codec is neither that nor the codec of the call has no kernel in this launch sequence: it
 // gets PQD_BAD_ARG here, so that its result is never what the memory held before.
@@ -927,47 +1195,53 @@ __global__ __launch_bounds__(256) void k_stored_pages(const pqd_decompress_desc*
   }
 }
 
-template <uint32_t WAVES, bool PIPE>
-static void launch_lz_waves(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
-  if (codec == PQD_CODEC_SNAPPY) {
-    if (PIPE)
-      hipLaunchKernelGGL((k_lz_pipe_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
-    else
-      hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_SNAPPY, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
-  } else if (codec == PQD_CODEC_LZ4_RAW) {
-    if (PIPE)
-      hipLaunchKernelGGL((k_lz_pipe_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
-    else
-      hipLaunchKernelGGL((k_lz_pages<PQD_CODEC_LZ4_RAW, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+// PIPE: 0 = the waves parse, then execute; 1 = parse and execution at once; 2 = table, chain, elements and execution at once
+template <int CODEC, uint32_t WAVES, int PIPE>
+static hipError_t launch_lz_kernel(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
+  if (PIPE == 2) {
+    // (more than 64 KB of LDS: asked for once per process and kernel)
+    static const hipError_t lds_fine =
+        hipFuncSetAttribute((const void*)k_lz_staged_pages<CODEC, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LwStagedLds));
+    if (lds_fine != hipSuccess) return lds_fine;
+    hipLaunchKernelGGL((k_lz_staged_pages<CODEC, WAVES>), dim3(n_pages), dim3(WAVES * 64), sizeof(LwStagedLds), stream, descs, results, n_pages);
+  } else if (PIPE == 1) {
+    hipLaunchKernelGGL((k_lz_pipe_pages<CODEC, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
+  } else {
+    hipLaunchKernelGGL((k_lz_pages<CODEC, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
   }
+  return hipGetLastError();
 }
 
-static void launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
-  // PQD_LZ_WAVES = 4, 8 or 16 fixes the waves per page, PQD_LZ_PIPE = 0 / 1 the kind of kernel (testing)
+template <uint32_t WAVES, int PIPE>
+static hipError_t launch_lz_waves(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
+  if (codec == PQD_CODEC_SNAPPY) return launch_lz_kernel<PQD_CODEC_SNAPPY, WAVES, PIPE>(descs, results, n_pages, stream);
+  if (codec == PQD_CODEC_LZ4_RAW) return launch_lz_kernel<PQD_CODEC_LZ4_RAW, WAVES, PIPE>(descs, results, n_pages, stream);
+  return hipSuccess;
+}
+
+static hipError_t launch_lz(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec, hipStream_t stream) {
+  // PQD_LZ_WAVES = 4, 8 or 16 fixes the waves per page, PQD_LZ_PIPE = 0 / 1 / 2 the kind of kernel (testing)
   const char* env = getenv("PQD_LZ_WAVES");
   const int forced = env ? atoi(env) : 0;
   const char* penv = getenv("PQD_LZ_PIPE");
-  const bool pipe = penv ? atoi(penv) != 0 : n_pages <= LW_PIPE4_PAGES;
+  const int pipe = penv ? atoi(penv) : n_pages <= LW_PIPE8_PAGES ? 2 : n_pages <= LW_PIPE4_PAGES ? 1 : 0;
   const uint32_t waves = forced == 4 || forced == 8 || forced == 16 ? (uint32_t)forced
-                         : !pipe                                   ? 4u
+                         : pipe == 0                               ? 4u
                          : n_pages <= LW_PIPE16_PAGES              ? 16u
                          : n_pages <= LW_PIPE8_PAGES               ? 8u
                                                                    : 4u;
-  if (pipe) {
-    if (waves == 16u)
-      launch_lz_waves<16u, true>(descs, results, n_pages, codec, stream);
-    else if (waves == 8u)
-      launch_lz_waves<8u, true>(descs, results, n_pages, codec, stream);
-    else
-      launch_lz_waves<4u, true>(descs, results, n_pages, codec, stream);
-    return;
+  if (pipe == 2) {  // (eight waves at least: three of them parse)
+    if (waves == 16u) return launch_lz_waves<16u, 2>(descs, results, n_pages, codec, stream);
+    return launch_lz_waves<8u, 2>(descs, results, n_pages, codec, stream);
   }
-  if (waves == 16u)
-    launch_lz_waves<16u, false>(descs, results, n_pages, codec, stream);
-  else if (waves == 8u)
-    launch_lz_waves<8u, false>(descs, results, n_pages, codec, stream);
-  else
-    launch_lz_waves<4u, false>(descs, results, n_pages, codec, stream);
+  if (pipe == 1) {
+    if (waves == 16u) return launch_lz_waves<16u, 1>(descs, results, n_pages, codec, stream);
+    if (waves == 8u) return launch_lz_waves<8u, 1>(descs, results, n_pages, codec, stream);
+    return launch_lz_waves<4u, 1>(descs, results, n_pages, codec, stream);
+  }
+  if (waves == 16u) return launch_lz_waves<16u, 0>(descs, results, n_pages, codec, stream);
+  if (waves == 8u) return launch_lz_waves<8u, 0>(descs, results, n_pages, codec, stream);
+  return launch_lz_waves<4u, 0>(descs, results, n_pages, codec, stream);
 }
 
 hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, int codec,
@@ -979,8 +1253,7 @@ hipError_t launch_decompress_pages(const pqd_decompress_desc* descs, pqd_page_re
     hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
     return hipGetLastError();
   }
-  launch_lz(descs, results, n_pages, codec, stream);
-  hipError_t e = hipGetLastError();
+  hipError_t e = launch_lz(descs, results, n_pages, codec, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_stored_pages, dim3(n_pages), dim3(256), 0, stream, descs, results, n_pages, (uint32_t)codec);
   return hipGetLastError();
