@@ -34,7 +34,14 @@ struct GzLds {
   uint16_t next[16];
   uint8_t lens[320];
   uint32_t crc_table[256];
+  // What a literal / length code of up to nine bits stands for, in one word: code bits | extra bits << 4 | kind << 8 |
+  // value << 16 (GZ_LITERAL: the byte; GZ_LENGTH: the base length; GZ_END; GZ_BAD: symbols 286 and 287), and the same
+  // for distance codes (kind GZ_LENGTH: the base distance; GZ_BAD: symbols 30 and 31).  0: the code is longer.
+  uint32_t lfast[1u << GZ_FAST_BITS], dfast[1u << GZ_FAST_BITS];
+  uint16_t lbase[32], dbase[32];  // the format's tables of bases and extra bits, out of memory
+  uint8_t lext[32], dext[32];
 };
+constexpr uint32_t GZ_LITERAL = 0u, GZ_LENGTH = 1u, GZ_END = 2u, GZ_BAD = 3u;
 
 __device__ const uint16_t GZ_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __device__ const uint8_t GZ_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -48,6 +55,35 @@ __device__ __forceinline__ uint32_t gz_peek(InStage& in, uint64_t bp) {
   const uint32_t byte = (uint32_t)(bp >> 3);
   in.reach(byte);
   return (uint32_t)(in.peek8(byte) >> ((uint32_t)bp & 7u));
+}
+
+// The same with the last eight bytes fetched kept in registers: a fetch every 25 to 32 bits instead of one per use.
+struct GzBits {
+  uint64_t held;     // stream bytes at_bit / 8 .. + 7
+  uint64_t at_bit;   // (a multiple of 8; ~0: nothing held)
+  __device__ __forceinline__ uint32_t peek(InStage& in, uint64_t bp) {
+    uint64_t off = bp - at_bit;
+    if (off > 32u) {  // (also when bp lies in front of what is held)
+      const uint32_t byte = (uint32_t)(bp >> 3);
+      in.reach(byte);
+      held = in.peek8(byte);
+      at_bit = (uint64_t)byte * 8u;
+      off = bp & 7u;
+    }
+    return (uint32_t)(held >> off);
+  }
+};
+
+// the table word of literal / length symbol `sym` whose code has `len` bits
+__device__ __forceinline__ uint32_t gz_lword(const GzLds& L, uint32_t sym, uint32_t len) {
+  if (sym < 256u) return len | (GZ_LITERAL << 8) | (sym << 16);
+  if (sym == 256u) return len | (GZ_END << 8);
+  if (sym >= 286u) return len | (GZ_BAD << 8);
+  return len | ((uint32_t)L.lext[sym - 257u] << 4) | (GZ_LENGTH << 8) | ((uint32_t)L.lbase[sym - 257u] << 16);
+}
+__device__ __forceinline__ uint32_t gz_dword(const GzLds& L, uint32_t sym, uint32_t len) {
+  if (sym >= 30u) return len | (GZ_BAD << 8);
+  return len | ((uint32_t)L.dext[sym] << 4) | (GZ_LENGTH << 8) | ((uint32_t)L.dbase[sym] << 16);
 }
 
 // Canonical code from the lengths lens[0..n): counts per length, symbols in code order, the look-up table of the codes
@@ -144,6 +180,25 @@ __device__ __forceinline__ int gz_symbol(InStage& in, uint64_t& bp, const uint16
   return -1;
 }
 
+// The symbol of a code of more than nine bits that starts the 32 bits `bits`; len = its length.  -1: no code matches.
+__device__ __forceinline__ int gz_long_symbol(uint32_t bits, const uint16_t* count, const uint16_t* symtab, uint32_t& len_out) {
+  int code = 0, first = 0, index = 0;
+  for (uint32_t len = 1; len <= 15; ++len) {
+    code |= (int)(bits & 1u);
+    bits >>= 1;
+    const int c = (int)uni(count[len]);
+    if (code - c < first) {
+      len_out = len;
+      return (int)uni(symtab[index + (code - first)]);
+    }
+    index += c;
+    first += c;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
 // mat * vec over GF(2): lane n < 32 holds row n of the matrix in `row`
 __device__ __forceinline__ uint32_t gz_gf2_times(uint32_t row, uint32_t vec) {
   uint32_t sum = 0;
@@ -216,6 +271,13 @@ __global__ __launch_bounds__(64) void k_gzip_pages(const pqd_decompress_desc* __
     for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
     L.crc_table[i] = c;
   }
+  if (lane < 32u) {
+    L.lbase[lane] = lane < 29u ? GZ_LBASE[lane] : (uint16_t)0;
+    L.lext[lane] = lane < 29u ? GZ_LEXT[lane] : (uint8_t)0;
+    L.dbase[lane] = lane < 30u ? GZ_DBASE[lane] : (uint16_t)0;
+    L.dext[lane] = lane < 30u ? GZ_DEXT[lane] : (uint8_t)0;
+  }
+  GzBits bits = {0ull, ~0ull};
   InStage in;
   in.base = (const PQD_GLOBAL uint8_t*)((uintptr_t)d.src & ~(uintptr_t)15);
   const uint32_t skew = (uint32_t)((uintptr_t)d.src & 15u);
@@ -382,32 +444,60 @@ __global__ __launch_bounds__(64) void k_gzip_pages(const pqd_decompress_desc* __
           err = gz_construct(L, L.dcount, L.dsym, L.dtab, L.lens + 288, ndist, lane);
           if (err && (err < 0 || ndist != (uint32_t)(uni(L.dcount[0]) + uni(L.dcount[1])))) GZ_FAIL();
         }
-        // ---- the block's symbols
+        // ---- the block's symbols: the two tables in words that hold everything a code stands for
+        for (uint32_t k = lane; k < (1u << GZ_FAST_BITS); k += 64u) {
+          const uint32_t el = L.ltab[k], ed = L.dtab[k];
+          L.lfast[k] = el ? gz_lword(L, el & 511u, el >> 9) : 0u;
+          L.dfast[k] = ed ? gz_dword(L, ed & 511u, ed >> 9) : 0u;
+        }
+        __syncthreads();
         for (;;) {
-          int sym = gz_symbol(in, bp, L.lcount, L.lsym, L.ltab);
-          if (sym < 0 || bp > end_bits) GZ_FAIL();
-          if (sym < 256) {
-            if (op + nl >= cap) GZ_FAIL();
-            mylit = lane == nl ? (uint32_t)sym : mylit;
-            if (++nl == 64u) GZ_FLUSH();
-          } else if (sym == 256) {
-            break;
-          } else {
-            sym -= 257;
-            if (sym >= 29) GZ_FAIL();
-            uint32_t extra;
-            GZ_TAKE(extra, (uint32_t)GZ_LEXT[sym]);
-            const uint32_t len = GZ_LBASE[sym] + extra;
-            const int ds = gz_symbol(in, bp, L.dcount, L.dsym, L.dtab);
-            if (ds < 0 || bp > end_bits || ds >= 30) GZ_FAIL();
-            GZ_TAKE(extra, (uint32_t)GZ_DEXT[ds]);
-            const uint32_t dist = GZ_DBASE[ds] + extra;
-            GZ_FLUSH();
-            if (dist > op - member_out) GZ_FAIL();  // too far back
-            if (len > cap - op) GZ_FAIL();
-            out.match(op, dist, len);
-            op += len;
+          const uint32_t b = bits.peek(in, bp);
+          uint32_t e = uni(L.lfast[b & ((1u << GZ_FAST_BITS) - 1u)]);
+          if (!e) {
+            uint32_t l = 0;
+            const int sym = gz_long_symbol(b, L.lcount, L.lsym, l);
+            if (sym < 0) GZ_FAIL();
+            e = gz_lword(L, (uint32_t)sym, l);
           }
+          const uint32_t l = e & 15u, kind = (e >> 8) & 3u;
+          if (kind == GZ_LITERAL) {
+            bp += l;
+            if (bp > end_bits) GZ_FAIL();
+            if (op + nl >= cap) GZ_FAIL();
+            mylit = lane == nl ? e >> 16 : mylit;
+            if (++nl == 64u) GZ_FLUSH();
+            continue;
+          }
+          if (kind == GZ_END) {
+            bp += l;
+            if (bp > end_bits) GZ_FAIL();
+            break;
+          }
+          if (kind == GZ_BAD) GZ_FAIL();
+          // a match: the length's extra bits lie in the 32 bits at hand (15 + 5 at most)
+          const uint32_t xl = (e >> 4) & 15u;
+          const uint32_t len = (e >> 16) + ((b >> l) & ((1u << xl) - 1u));
+          bp += l + xl;
+          if (bp > end_bits) GZ_FAIL();
+          const uint32_t c = bits.peek(in, bp);
+          uint32_t f = uni(L.dfast[c & ((1u << GZ_FAST_BITS) - 1u)]);
+          if (!f) {
+            uint32_t dl = 0;
+            const int ds = gz_long_symbol(c, L.dcount, L.dsym, dl);
+            if (ds < 0) GZ_FAIL();
+            f = gz_dword(L, (uint32_t)ds, dl);
+          }
+          if (((f >> 8) & 3u) == GZ_BAD) GZ_FAIL();
+          const uint32_t dl = f & 15u, xd = (f >> 4) & 15u;  // (15 + 13 bits at most)
+          const uint32_t dist = (f >> 16) + ((c >> dl) & ((1u << xd) - 1u));
+          bp += dl + xd;
+          if (bp > end_bits) GZ_FAIL();
+          GZ_FLUSH();
+          if (dist > op - member_out) GZ_FAIL();  // too far back
+          if (len > cap - op) GZ_FAIL();
+          out.match(op, dist, len);
+          op += len;
         }
       } else {
         GZ_FAIL();
