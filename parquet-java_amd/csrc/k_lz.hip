@@ -812,8 +812,9 @@ __device__ __forceinline__ bool lw_snappy_preamble(const PQD_GLOBAL uint8_t* src
   return false;
 }
 
+// (with four waves: registers for seven waves per SIMD, so that seven pages a CU are in flight)
 template <int CODEC, uint32_t WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4u ? 7 : 1) void k_lz_pages(const pqd_decompress_desc* __restrict__ descs,
                                                             pqd_page_result* __restrict__ results, uint32_t n_pages) {
   __shared__ LwLds L;
   const uint32_t page = blockIdx.x;

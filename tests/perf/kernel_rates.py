@@ -340,7 +340,7 @@ def byte_arrays():
 
 
 def decompression():
-    """SNAPPY / LZ4_RAW / ZSTD pages of 1 MiB (parquet-java's default page size), compressed with the C libraries through pyarrow."""
+    """SNAPPY / LZ4_RAW / ZSTD / GZIP pages of 1 MiB (parquet-java's default page size), compressed with the C libraries through pyarrow."""
     if ONLY and ONLY not in "decompress":
         return
     import pyarrow as pa
@@ -357,7 +357,7 @@ def decompression():
     def doubles(r):
         return np.round(r.normal(size=size // 8), 2).astype("<f8").tobytes()
     for kind, make in (("text", text), ("int32 < 1000", ints), ("doubles, 2 decimals", doubles)):
-        for codec, num in (("snappy", 1), ("lz4_raw", 7), ("zstd", 6)):
+        for codec, num in (("snappy", 1), ("lz4_raw", 7), ("zstd", 6), ("gzip", 2)):
             n_p = int(os.environ.get("KR_LZ_PAGES", "1792"))
             pages = distinct_pages(lambda r: pa.Codec(codec).compress(make(r), asbytes=True), n_p)
             offs = np.cumsum([0] + [p.size for p in pages])
