@@ -60,6 +60,9 @@ constexpr uint16_t LW_HAS = 0x8000u;  // a tile cell that holds its byte
 #ifndef LW_UNROLL
 #define LW_UNROLL 4u
 #endif
+#ifndef LW_HOPS
+#define LW_HOPS 2u  // pointers followed per round of a tile's resolution
+#endif
 // Kernel and waves per page by the size of the call.  A page's time is that of its serial chains (the parse: table,
 // chain, elements; the steps of its tiles) rather than the CU's throughput, so few pages get many waves each:
 //   at most 512 pages: k_lz_staged_pages, a wave for each of the parse's three steps and 13 (at most 256 pages) or 5
@@ -586,6 +589,13 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
           for (uint32_t u = 0; u < UN; ++u) mine_[u] = t0 + u < n_steps ? cell[(t0 + u) * 64u + lane] : LW_HAS;
 #pragma unroll
           for (uint32_t u = 0; u < UN; ++u) other[u] = (mine_[u] & LW_HAS) ? LW_HAS : cell[mine_[u]];
+          // (LW_HOPS pointers a round: chains inside a tile are short, and a look-up costs less than a round)
+#pragma unroll
+          for (uint32_t h = 1; h < LW_HOPS; ++h) {
+#pragma unroll
+            for (uint32_t u = 0; u < UN; ++u)
+              if (!(other[u] & LW_HAS)) other[u] = cell[other[u]];
+          }
 #pragma unroll
           for (uint32_t u = 0; u < UN; ++u) {
             if (!(mine_[u] & LW_HAS)) {
