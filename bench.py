@@ -314,6 +314,45 @@ def config1_sweep(device, stream, timed, n_pages=256, n_values=1_000_000):
             "note": "algorithmic bytes = encoded page + 4 bytes per value; distinct pages (2.0 GiB decoded per call: beyond the 256 MiB Infinity Cache)"}
 
 
+def page_decompression(device, stream, timed, n_pages=256, size=1 << 20):
+    """pqd_decompress_pages_dev on n_pages pages of 1 MiB (parquet-java's default page size; 16 distinct ones), compressed
+    on the host by the C libraries through pyarrow: GB/s of output, every distinct page compared with its original.
+    Replaces the decompressor call in front of initFromPage (ColumnChunkPageReadStore.java:151-181, :232-262)."""
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return {"skipped": "pyarrow is not importable here: no compressor to make the pages with"}
+    distinct = 16
+    words = [bytes(np.random.default_rng(1).integers(97, 123, k, dtype=np.uint8)) for k in np.random.default_rng(2).integers(2, 10, 2000)]
+    kinds = {
+        "text": lambda r: b" ".join(words[i] for i in r.integers(0, 2000, size // 5))[:size],
+        "int32_below_1000": lambda r: r.integers(0, 1000, size // 4).astype("<i4").tobytes(),
+    }
+    out = {"pages": n_pages, "page_bytes": size}
+    for kind, make in kinds.items():
+        raws = [make(np.random.default_rng(100 + i)) for i in range(distinct)]
+        for codec, num in (("snappy", 1), ("lz4_raw", 7), ("zstd", 6), ("gzip", 2)):
+            comp = [np.frombuffer(pa.Codec(codec).compress(r, asbytes=True), np.uint8) for r in raws]
+            pages = [comp[i % distinct] for i in range(n_pages)]
+            offs = np.cumsum([0] + [p.size for p in pages])
+            blob = torch.from_numpy(np.concatenate(pages + [np.zeros(64, np.uint8)])).to(device)
+            dst = torch.zeros((n_pages, size), dtype=torch.uint8, device=device)
+            d = (pq.DecompressDesc * n_pages)()
+            for i in range(n_pages):
+                d[i].src, d[i].dst, d[i].src_len, d[i].dst_len, d[i].codec = blob.data_ptr() + int(offs[i]), dst[i].data_ptr(), pages[i].size, size, num
+            d_d = torch.from_numpy(np.frombuffer(bytes(d), np.uint8).copy()).to(device)
+            res = torch.zeros(n_pages * 16, dtype=torch.uint8, device=device)
+            ms = timed(lambda: pq.check(pq.lib.pqd_decompress_pages_dev(d_d.data_ptr(), res.data_ptr(), n_pages, num, stream)), iters=3)
+            r = res.cpu().numpy().view(np.uint32).reshape(-1, 4)
+            ok = bool((r[:, 0] == 0).all() and (r[:, 1] == size).all())
+            for i in range(distinct):
+                ok = ok and bytes(dst[n_pages - distinct + i].cpu().numpy()) == raws[(n_pages - distinct + i) % distinct]
+            out[f"{codec}_{kind}"] = {"ms": round(ms, 3), "GBps_out": round(n_pages * size / ms / 1e6, 1),
+                                      "ratio": round(n_pages * size / float(offs[-1]), 2), "verified": ok}
+            del blob, dst
+    return out
+
+
 def config5_shard(device, stream, timed, rank=0):
     """BASELINE.json configs[4], one GPU's share: 512 row groups x 20 mixed-encoding column chunks dealt round
     robin over 8 GPUs = 64 row groups x 20 chunks x 250 000 values here (dictionary INT32 / INT64, DELTA_BINARY_PACKED,
@@ -627,6 +666,7 @@ def main():
         binary["offsets"] = binary["bytes"] = None
         torch.cuda.empty_cache()
         extras["config5_shard"] = config5_shard(device, stream, timed, rank)
+        extras["page_decompression_256_pages_of_1MiB"] = page_decompression(device, stream, timed)
         if not args.no_config1:
             for c in cols:  # make room: the columns of the timed region are no longer needed
                 c["out"] = c["blob"] = c["ids"] = None
