@@ -65,12 +65,15 @@ constexpr uint16_t LW_HAS = 0x8000u;  // a tile cell that holds its byte
 #endif
 // Kernel and waves per page by the size of the call.  A page's time is that of its serial chains (the parse: table,
 // chain, elements; the steps of its tiles) rather than the CU's throughput, so few pages get many waves each:
-//   at most 512 pages: k_lz_staged_pages, a wave for each of the parse's three steps and 13 (at most 256 pages) or 5
-//                      for the execution, all at once on four successive windows (77 KB of LDS: two pages a CU);
+//   at most 256 pages: k_lz_staged_pages with sixteen waves: the table's two halves, the chain and the elements by a
+//                      wave each, twelve for the execution, all at once on five successive windows (95 KB of LDS: a
+//                      page a CU);
+//   at most 512 pages: the same with eight waves: table, chain, elements, five for the execution (77 KB: two pages a CU);
 //   at most 768 pages: k_lz_pipe_pages, one wave parses while three execute the window before (52 KB: three pages a CU);
-//   more:              k_lz_pages, four waves that parse, then execute (22.5 KB, 72 VGPRs: seven pages a CU).
-// 1 MiB pages of text / small integers / doubles, Snappy: 256 pages 82 / 76 / 70 GB/s (k_lz_pages with 16 waves: 45 /
-// 29 / 36), 512 pages 97 / 108 / 101, 768 pages 108 / 95 / 115, 1792 pages 154 / 135 / 157; LZ4 about a tenth less.
+//   more:              k_lz_pages, four waves that parse, then execute (22.5 KB, 68 VGPRs: seven pages a CU).
+// 1 MiB pages of text / small integers / doubles, Snappy: 256 pages 85 / 83 / 71 GB/s (k_lz_pages with 16 waves: 45 /
+// 29 / 36), 512 pages 100 / 107 / 102, 768 pages 110 / 91 / 117, 1792 pages 160 / 130 / 153; LZ4: 73 / 90 / 63,
+// 96 / 100 / 96, 112 / 90 / 108, 147 / 137 / 139.
 constexpr uint32_t LW_PIPE16_PAGES = 256, LW_PIPE8_PAGES = 512, LW_PIPE4_PAGES = 768;
 
 __device__ __forceinline__ uint32_t lw_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -151,19 +154,22 @@ struct LwChainRecord {
 // Four windows in flight, a wave for each of the parse's three serial steps: the first makes the table of places of a
 // window (windows then start at multiples of LW_WIN, so that a table does not depend on where the chain enters it),
 // the second follows the chain through the window before it, the third lists the elements of the one before that, the
-// others execute the one before that (76 KB: two pages a CU).
-struct LwStagedLds {
-  __attribute__((aligned(16))) uint8_t win_[4][LW_WIN + LW_SLACK + 32];
-  u32x2 place_[2][64 * 33];
+// others execute the one before that (76 KB: two pages a CU).  SPLIT: five windows, the table's upper and lower half
+// by a wave each, one after the other (95 KB: for the workgroups of sixteen waves, which have a CU to themselves).
+template <bool SPLIT>
+struct LwStagedLdsT {
+  static constexpr uint32_t WIN_SLOTS = SPLIT ? 5u : 4u, PLACE_SLOTS = SPLIT ? 3u : 2u;
+  __attribute__((aligned(16))) uint8_t win_[WIN_SLOTS][LW_WIN + LW_SLACK + 32];
+  u32x2 place_[PLACE_SLOTS][64 * 33];
   LwChainRecord k_[2];
   LwElems e_[2];
   __attribute__((aligned(16))) uint16_t cell_[LW_TILE];
   LwTiles t;
-  // (a tile's first 512 bytes, before its cells are written)
-  __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(cell_); }
   LwWindow w_[2];
   uint32_t after_ip, after_op, after_failed;
   uint32_t arrived, abort;
+  // (a tile's first 512 bytes, before its cells are written)
+  __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(cell_); }
   __device__ __forceinline__ uint8_t* win(uint32_t s) { return win_[s]; }
   __device__ __forceinline__ u32x2* place(uint32_t s) { return place_[s]; }
   __device__ __forceinline__ LwChainRecord& chain(uint32_t s) { return k_[s]; }
@@ -325,11 +331,14 @@ __device__ __forceinline__ uint32_t lw_staged_end(uint32_t w0, uint32_t in_end) 
 // The table of places of the window that starts at stream position w0 (its bytes lie in `win`), by one wave:
 // the places of this lane's segment, last to first, two at a time (a sequence is two bytes or more, so neither of the
 // two continues at the other; the one exception is dealt with below).
+// (first / last: the places first, first - 1 .. last, last - 1 of every segment, for two waves that make a table's
+// upper and lower half one after the other)
 template <int CODEC>
-__device__ __forceinline__ void lw_places(const uint8_t* win, u32x2* place, uint32_t w0, uint32_t in_end, uint32_t lane) {
+__device__ __forceinline__ void lw_places(const uint8_t* win, u32x2* place, uint32_t w0, uint32_t in_end, uint32_t lane, int first = 31,
+                                          int last = 1) {
   const uint32_t staged = lw_staged_end(w0, in_end);
   const uint32_t seg = w0 + lane * 32u;
-  for (int pl = 31; pl >= 1; pl -= 2) {
+  for (int pl = first; pl >= last; pl -= 2) {
     LwSeq s[2];
     uint32_t j[2];
     u32x2 at_j[2];
@@ -484,7 +493,9 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
                                            uint32_t lane, BAR& bar LW_PROF_ARGS) {
   constexpr uint32_t NW = XWAVES;  // waves that share the bytes of a tile
   // steps of 64 bytes a wave takes at a time: the 64 steps of a tile are shared out evenly
-  constexpr uint32_t UN = NW >= 16u ? 4u : NW >= 13u ? 5u : NW >= 11u ? 6u : LW_UNROLL;
+  constexpr uint32_t UN = NW >= 16u ? 4u : NW >= 12u ? 5u : LW_UNROLL;
+  // a tile is as many steps (of 64 at most) as the waves take in whole turns
+  constexpr uint32_t TILE = NW * UN >= 64u ? LW_TILE : (64u / (NW * UN)) * (NW * UN) * 64u;
   const LwWindow W = L.window(slot);
   const uint8_t* win = L.win(W.win_slot);
   const LwElems& E = L.elems(slot);
@@ -495,7 +506,7 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
   uint32_t e_lo = 0;  // (the first wave's: elements below it start at or in front of the tile)
   // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane
   auto masks = [&](uint32_t tb, LwTiles& T) {
-    const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
+    const uint32_t te = o1 - tb < TILE ? o1 : tb + TILE;
     start_bits[lane] = 0;
     start_bits[lane + 64u] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -524,8 +535,8 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
     T.t_hi[lane] = hi;
     T.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
   };
-  for (uint32_t tb = o0; tb < o1; tb += LW_TILE) {
-    const uint32_t te = o1 - tb < LW_TILE ? o1 : tb + LW_TILE;
+  for (uint32_t tb = o0; tb < o1; tb += TILE) {
+    const uint32_t te = o1 - tb < TILE ? o1 : tb + TILE;
     const LwTiles& T = L.t;
     if (xw == 0) masks(tb, L.t);
     bar.sync();
@@ -996,16 +1007,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pipe_pages(const pqd_decompre
 }
 
 // The same with the three serial steps of the parse and the execution going on at once, each on the window behind
-// the next step's: table (first wave), chain (second), elements (third), execution (the other WAVES - 3); a workgroup
-// barrier once per window.  The chain may leave a window far behind the next one (a long literal): the table made
-// meanwhile is then of no use, and the next one is made where the chain arrived.  The chain runs ahead of the check of
-// the sequences it passes (the listing of the elements): when that stops in front of a sequence, what was chained
-// behind it does not count.
-template <int CODEC, uint32_t WAVES>
+// the next step's: table (first wave; SPLIT: its upper half by the first, its lower half a step later by the second),
+// chain, elements, execution (all other waves); a workgroup barrier once per window.  The chain may leave a window far
+// behind the next one (a long literal): the tables made meanwhile are then of no use, and the next one is made where
+// the chain arrived.  The chain runs ahead of the check of the sequences it passes (the listing of the elements): when
+// that stops in front of a sequence, what was chained behind it does not count.
+template <int CODEC, uint32_t WAVES, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decompress_desc* __restrict__ descs,
                                                                    pqd_page_result* __restrict__ results, uint32_t n_pages) {
+  using Lds = LwStagedLdsT<SPLIT>;
+  constexpr uint32_t PARSERS = SPLIT ? 4u : 3u, WS = Lds::WIN_SLOTS, PS = Lds::PLACE_SLOTS;
+  constexpr uint32_t W_LOWER = 1u, W_CHAIN = PARSERS - 2u, W_ELEMS = PARSERS - 1u;  // (W_LOWER only with SPLIT)
   extern __shared__ __attribute__((aligned(16))) uint8_t lw_staged_lds[];
-  LwStagedLds& L = *reinterpret_cast<LwStagedLds*>(lw_staged_lds);
+  Lds& L = *reinterpret_cast<Lds*>(lw_staged_lds);
   const uint32_t page = blockIdx.x;
   if (page >= n_pages) return;
   const pqd_decompress_desc d = descs[page];
@@ -1034,25 +1048,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
     L.abort = 0;
   }
   __syncthreads();
-  LwExecWaves bar = {&L.arrived, &L.abort, 0u, WAVES - 3u, lane};
+  LwExecWaves bar = {&L.arrived, &L.abort, 0u, WAVES - PARSERS, lane};
   uint32_t cip = ip, cop = op;  // where the chain has arrived
   bool parse_on = true;     // false: a window stopped in front of a sequence that is to be taken by itself
-  bool tab_valid = false;   // a table is made and not used yet: that of window tab_grid, the tab_seq-th made
+  bool tab_valid = false;   // a table is made and not used yet: that of window tab_grid, the tab_seq-th begun
   uint32_t tab_grid = 0, tab_seq = 0;
+  bool hi_valid = false;    // (SPLIT) a table's upper half is made
+  uint32_t hi_grid = 0, hi_seq = 0;
   bool chain_valid = false;  // a window is chained and its elements are not listed yet
-  uint32_t a_seq = 0, b_seq = 0, c_seq = 0;  // tables made, windows chained, windows listed
+  uint32_t a_seq = 0, b_seq = 0, c_seq = 0;  // tables begun, windows chained, windows listed
   int x_slot = -1;          // the listed window that has not been executed yet
   uint32_t dog7 = 0;
   while (status == PQD_OK) {
     LW_DOG(dog7, 7)
     const bool more = parse_on && cip < in_end;
-    const uint32_t grid = cip / LW_WIN;
-    const bool b_work = more && tab_valid && tab_grid == grid;
-    // the table to make: of the window behind the one that is being chained, or of the one the chain has arrived in
-    const uint32_t a_grid = b_work ? tab_grid + 1u : grid;
+    const uint32_t need = cip / LW_WIN;
+    // tables (whole ones, half ones) that do not lie where the chain goes on are of no use
+    if (tab_valid && tab_grid != need) tab_valid = false;
+    if (hi_valid && hi_grid != need + (tab_valid ? 1u : 0u)) hi_valid = false;
+    const bool b_work = more && tab_valid;
+    const bool lo_work = more && hi_valid;
+    // the table to begin: of the window behind those that are on their way
+    const uint32_t a_grid = need + (tab_valid ? 1u : 0u) + (hi_valid ? 1u : 0u);
     const bool a_work = more && a_grid * LW_WIN < in_end;
     const bool c_work = chain_valid;
-    if (!a_work && !b_work && !c_work && x_slot < 0) {
+    if (!a_work && !lo_work && !b_work && !c_work && x_slot < 0) {
       if (parse_on || ip >= in_end) break;  // the stream is used up
       // one sequence by the first wave (everything in front of it is in memory); the others learn where it ended
       if (wave == 0) {
@@ -1078,27 +1098,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
       if (a_work) {
         LW_TICK
         const uint32_t w0 = a_grid * LW_WIN;
-        uint8_t* win = L.win(a_seq & 3u);
+        uint8_t* win = L.win(a_seq % WS);
         lw_stage(win, src, w0, lw_staged_end(w0, in_end), lane * 16u, 1024u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         LW_STAMP(0)
-        lw_places<CODEC>(win, L.place(a_seq & 1u), w0, in_end, lane);
+        lw_places<CODEC>(win, L.place(a_seq % PS), w0, in_end, lane, 31, SPLIT ? 17 : 1);
         LW_STAMP(1)
       }
-    } else if (wave == 1) {
+    } else if (SPLIT && wave == W_LOWER) {
+      if (lo_work) lw_places<CODEC>(L.win(hi_seq % WS), L.place(hi_seq % PS), hi_grid * LW_WIN, in_end, lane, 15, 1);
+    } else if (wave == W_CHAIN) {
       if (b_work) {
         LW_TICK
         LwChainRecord& K = L.chain(b_seq & 1u);
         uint32_t next_ip, next_op;
-        const LwChained c = lw_chain(L.place(tab_seq & 1u), tab_grid * LW_WIN, cip, cop, in_end, cap, lane, next_ip, next_op);
+        const LwChained c = lw_chain(L.place(tab_seq % PS), tab_grid * LW_WIN, cip, cop, in_end, cap, lane, next_ip, next_op);
         K.entry[lane] = c.entry;
         K.first_elem[lane] = c.first_elem;
         K.first_out[lane] = c.first_out;
         if (lane == 0) {
           K.w0 = tab_grid * LW_WIN;
-          K.win_slot = tab_seq & 3u;
+          K.win_slot = tab_seq % WS;
           K.ip = cip;
           K.op = cop;
           K.next_ip = next_ip;
@@ -1106,7 +1128,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
         }
         LW_STAMP(2)
       }
-    } else if (wave == 2) {
+    } else if (wave == W_ELEMS) {
       if (c_work) {
         LW_TICK
         const LwChainRecord& K = L.chain((b_seq - 1u) & 1u);
@@ -1116,7 +1138,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
       }
     } else if (x_slot >= 0) {
       LW_TICK
-      lw_execute<WAVES - 3u>(L, (uint32_t)x_slot, src, dst, wave - 3u, lane, bar LW_PROF_PASS);
+      lw_execute<WAVES - PARSERS>(L, (uint32_t)x_slot, src, dst, wave - PARSERS, lane, bar LW_PROF_PASS);
     }
     __syncthreads();
     x_slot = -1;
@@ -1141,7 +1163,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
       ++b_seq;
       tab_valid = false;
     }
-    if (a_work) {
+    if (SPLIT) {
+      if (lo_work) {  // (the table before it has just been chained, or was of no use)
+        tab_valid = true;
+        tab_grid = hi_grid;
+        tab_seq = hi_seq;
+        hi_valid = false;
+      }
+      if (a_work) {
+        hi_valid = true;
+        hi_grid = a_grid;
+        hi_seq = a_seq;
+        ++a_seq;
+      }
+    } else if (a_work) {
       tab_valid = true;
       tab_grid = a_grid;
       tab_seq = a_seq;
@@ -1151,6 +1186,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
       if (stopped) parse_on = false;
       chain_valid = false;
       tab_valid = false;
+      hi_valid = false;
       cip = ip;
       cop = op;
     }
@@ -1168,9 +1204,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
   if (cap >= 64u) {
     if (tid == 0)
       for (int k = 0; k < 2; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
-    if (tid == 64u) ((PQD_GLOBAL uint64_t*)d.dst)[2] = prof[2];
-    if (tid == 128u) ((PQD_GLOBAL uint64_t*)d.dst)[3] = prof[3];
-    if (tid == 192u)
+    if (tid == W_CHAIN * 64u) ((PQD_GLOBAL uint64_t*)d.dst)[2] = prof[2];
+    if (tid == W_ELEMS * 64u) ((PQD_GLOBAL uint64_t*)d.dst)[3] = prof[3];
+    if (tid == PARSERS * 64u)
       for (int k = 4; k < 8; ++k) ((PQD_GLOBAL uint64_t*)d.dst)[k] = prof[k];
   }
 #endif
@@ -1211,10 +1247,13 @@ template <int CODEC, uint32_t WAVES, int PIPE>
 static hipError_t launch_lz_kernel(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (PIPE == 2) {
     // (more than 64 KB of LDS: asked for once per process and kernel)
-    static const hipError_t lds_fine =
-        hipFuncSetAttribute((const void*)k_lz_staged_pages<CODEC, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LwStagedLds));
+    // (sixteen waves: a CU to themselves, the table's halves by two waves)
+    constexpr bool SPLIT = WAVES == 16u;
+    static const hipError_t lds_fine = hipFuncSetAttribute((const void*)k_lz_staged_pages<CODEC, WAVES, SPLIT>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LwStagedLdsT<SPLIT>));
     if (lds_fine != hipSuccess) return lds_fine;
-    hipLaunchKernelGGL((k_lz_staged_pages<CODEC, WAVES>), dim3(n_pages), dim3(WAVES * 64), sizeof(LwStagedLds), stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_lz_staged_pages<CODEC, WAVES, SPLIT>), dim3(n_pages), dim3(WAVES * 64), sizeof(LwStagedLdsT<SPLIT>), stream, descs,
+                       results, n_pages);
   } else if (PIPE == 1) {
     hipLaunchKernelGGL((k_lz_pipe_pages<CODEC, WAVES>), dim3(n_pages), dim3(WAVES * 64), 0, stream, descs, results, n_pages);
   } else {

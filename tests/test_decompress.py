@@ -557,11 +557,11 @@ def test_gpu_lz4_stream_that_ends_with_a_lone_token(orc):
 @pytest.mark.parametrize("kernel", ["staged8", "pipe4", "pipe16", "serial4", "serial16"])
 @pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
 def test_gpu_lz_pages_with_other_kernels_and_waves(orc, monkeypatch, codec_name, kernel):
-    """Calls of few pages (every test here) take the Snappy / LZ4 kernel whose first three waves make the table of a
-    window, follow the chain through the one before and list the elements of the one before that while thirteen others
-    execute a fourth; calls of up to 512 pages take it with eight waves, up to 768 the kernel whose first wave parses
-    while three others execute, larger ones the kernel whose four waves parse, then execute: the same streams with
-    kernel and waves fixed."""
+    """Calls of few pages (every test here) take the Snappy / LZ4 kernel whose first four waves make the two halves of
+    a window's table, follow the chain through the window before and list the elements of the one before that while
+    twelve others execute a fifth; calls of up to 512 pages take it with eight waves (the table by one wave), up to 768
+    the kernel whose first wave parses while three others execute, larger ones the kernel whose four waves parse, then
+    execute: the same streams with kernel and waves fixed."""
     monkeypatch.setenv("PQD_LZ_PIPE", {"serial": "0", "pipe": "1", "staged": "2"}[kernel.rstrip("0123456789")])
     monkeypatch.setenv("PQD_LZ_WAVES", kernel.lstrip("pipeserialstaged"))
     test_gpu_decompresses_library_streams_and_pages(orc, codec_name)
