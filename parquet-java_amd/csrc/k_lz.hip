@@ -166,10 +166,17 @@ struct LwStagedLdsT {
   __attribute__((aligned(16))) uint16_t cell_[LW_TILE];
   LwTiles t;
   LwWindow w_[2];
+  // the masks of a listed window's first tiles, made by the wave that lists the elements (two tiles without SPLIT: what
+  // LDS is left with two pages a CU)
+  static constexpr uint32_t READY_TILES = SPLIT ? 4u : 2u;
+  LwTiles ready_[2][READY_TILES];
+  uint32_t n_ready[2];
+  uint32_t parse_bits[128];
   uint32_t after_ip, after_op, after_failed;
   uint32_t arrived, abort;
   // (a tile's first 512 bytes, before its cells are written)
   __device__ __forceinline__ uint32_t* bits() { return reinterpret_cast<uint32_t*>(cell_); }
+  __device__ __forceinline__ LwTiles* ready(uint32_t s) { return ready_[s]; }
   __device__ __forceinline__ uint8_t* win(uint32_t s) { return win_[s]; }
   __device__ __forceinline__ u32x2* place(uint32_t s) { return place_[s]; }
   __device__ __forceinline__ LwChainRecord& chain(uint32_t s) { return k_[s]; }
@@ -486,16 +493,58 @@ __device__ __forceinline__ void lw_parse_window(LDS& L, uint32_t slot, uint32_t 
   lw_chain_elements<CODEC>(L.win(slot), L.place(), L.elems(slot), &L.window(slot), slot, ip, ip, op, in_end, cap, lane LW_PROF_PASS);
 }
 
+// steps of 64 bytes that one of nw executing waves takes at a time: the steps of a tile are shared out evenly
+__host__ __device__ constexpr uint32_t lw_steps_at_a_time(uint32_t nw) { return nw >= 16u ? 4u : nw >= 12u ? 5u : LW_UNROLL; }
+// a tile is as many steps (of 64 at most) as nw waves take in whole turns
+__host__ __device__ constexpr uint32_t lw_tile_bytes(uint32_t nw) {
+  return nw * lw_steps_at_a_time(nw) >= 64u ? LW_TILE : (64u / (nw * lw_steps_at_a_time(nw))) * (nw * lw_steps_at_a_time(nw)) * 64u;
+}
+
+// The element starts inside the tile (tb, tb + tile) of a window's output as bit masks, 64 bytes of the tile per lane,
+// by one wave.  e_lo: elements below it start at or in front of the tile (kept from tile to tile; 0 is always right).
+// bits: 128 words of LDS for this wave alone.
+__device__ __forceinline__ void lw_tile_masks(const LwElems& E, uint32_t n_elems, uint32_t o1, uint32_t tb, uint32_t tile, uint32_t& e_lo,
+                                              uint32_t* bits, LwTiles& T, uint32_t lane) {
+  const uint32_t te = o1 - tb < tile ? o1 : tb + tile;
+  bits[lane] = 0;
+  bits[lane + 64u] = 0;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t dog3 = 0;
+  for (;;) {
+    LW_DOG(dog3, 3)
+    const uint32_t i = e_lo + lane;
+    const bool in_front = i < n_elems && E.e_out[i] <= tb;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
+    e_lo += (uint32_t)__builtin_popcountll(m);
+    if (m != ~0ull) break;
+  }
+  uint32_t dog4 = 0;
+  for (uint32_t b = e_lo;; b += 64u) {
+    LW_DOG(dog4, 4)
+    const uint32_t i = b + lane;
+    const uint32_t eo = i < n_elems ? E.e_out[i] : 0xFFFFFFFFu;
+    const bool inside = eo < te;
+    if (inside) atomicOr(&bits[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
+    if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t lo = bits[2u * lane], hi = bits[2u * lane + 1u];
+  const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
+  T.t_lo[lane] = lo;
+  T.t_hi[lane] = hi;
+  T.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The output of a parsed window, tile by tile, by XWAVES waves (this one is number xw of them); bar.sync() is their
-// barrier.  The tiles are in memory when it returns.
+// barrier.  The tiles are in memory when it returns.  ready[0 .. n_ready): the masks of the window's first tiles, where
+// the parse has made them already.
 template <uint32_t XWAVES, class LDS, class BAR>
 __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOBAL uint8_t* src, PQD_GLOBAL uint8_t* dst, uint32_t xw,
-                                           uint32_t lane, BAR& bar LW_PROF_ARGS) {
+                                           uint32_t lane, BAR& bar, const LwTiles* ready, uint32_t n_ready LW_PROF_ARGS) {
   constexpr uint32_t NW = XWAVES;  // waves that share the bytes of a tile
-  // steps of 64 bytes a wave takes at a time: the 64 steps of a tile are shared out evenly
-  constexpr uint32_t UN = NW >= 16u ? 4u : NW >= 12u ? 5u : LW_UNROLL;
-  // a tile is as many steps (of 64 at most) as the waves take in whole turns
-  constexpr uint32_t TILE = NW * UN >= 64u ? LW_TILE : (64u / (NW * UN)) * (NW * UN) * 64u;
+  constexpr uint32_t UN = lw_steps_at_a_time(NW);
+  constexpr uint32_t TILE = lw_tile_bytes(NW);
   const LwWindow W = L.window(slot);
   const uint8_t* win = L.win(W.win_slot);
   const LwElems& E = L.elems(slot);
@@ -504,42 +553,15 @@ __device__ __forceinline__ void lw_execute(LDS& L, uint32_t slot, const PQD_GLOB
   uint16_t* cell = L.cell();
   uint32_t* start_bits = L.bits();
   uint32_t e_lo = 0;  // (the first wave's: elements below it start at or in front of the tile)
-  // element starts inside (tb, te) as bit masks, 64 bytes of the tile per lane
-  auto masks = [&](uint32_t tb, LwTiles& T) {
+  uint32_t ti = 0;
+  for (uint32_t tb = o0; tb < o1; tb += TILE, ++ti) {
     const uint32_t te = o1 - tb < TILE ? o1 : tb + TILE;
-    start_bits[lane] = 0;
-    start_bits[lane + 64u] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t dog3 = 0;
-    for (;;) {
-      LW_DOG(dog3, 3)
-      const uint32_t i = e_lo + lane;
-      const bool in_front = i < n_elems && E.e_out[i] <= tb;
-      const uint64_t m = __builtin_amdgcn_ballot_w64(in_front);
-      e_lo += (uint32_t)__builtin_popcountll(m);
-      if (m != ~0ull) break;
+    const bool have = ti < n_ready;
+    const LwTiles& T = have ? ready[ti] : L.t;
+    if (!have) {
+      if (xw == 0) lw_tile_masks(E, n_elems, o1, tb, TILE, e_lo, start_bits, L.t, lane);
+      bar.sync();
     }
-    uint32_t dog4 = 0;
-    for (uint32_t b = e_lo;; b += 64u) {
-      LW_DOG(dog4, 4)
-      const uint32_t i = b + lane;
-      const uint32_t eo = i < n_elems ? E.e_out[i] : 0xFFFFFFFFu;
-      const bool inside = eo < te;
-      if (inside) atomicOr(&start_bits[(eo - tb) >> 5], 1u << ((eo - tb) & 31u));
-      if (__builtin_amdgcn_ballot_w64(inside) != ~0ull) break;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t lo = start_bits[2u * lane], hi = start_bits[2u * lane + 1u];
-    const uint32_t in_seg = (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-    T.t_lo[lane] = lo;
-    T.t_hi[lane] = hi;
-    T.t_before[lane] = e_lo - 1u + wave_scan_inclusive(in_seg) - in_seg;  // the element of the byte in front of the segment
-  };
-  for (uint32_t tb = o0; tb < o1; tb += TILE) {
-    const uint32_t te = o1 - tb < TILE ? o1 : tb + TILE;
-    const LwTiles& T = L.t;
-    if (xw == 0) masks(tb, L.t);
-    bar.sync();
     LW_STAMP(4)
     const uint32_t a = (uint32_t)((uintptr_t)(dst + tb) & 15u);
     const uint64_t upto = (2ull << lane) - 1ull;
@@ -671,7 +693,7 @@ __device__ __forceinline__ bool lw_window(LwLds& L, const PQD_GLOBAL uint8_t* sr
   if (wave == 0) lw_parse_window<CODEC>(L, 0u, ip, op, in_end, cap, lane LW_PROF_PASS);
   __syncthreads();
   LwAllWaves bar;
-  lw_execute<WAVES>(L, 0u, src, dst, wave, lane, bar LW_PROF_PASS);
+  lw_execute<WAVES>(L, 0u, src, dst, wave, lane, bar, nullptr, 0u LW_PROF_PASS);
   const LwWindow W = L.window(0);  // (rewritten behind the next window's first barrier)
   op = W.out_end;
   ip = W.new_ip;
@@ -974,7 +996,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_pipe_pages(const pqd_decompre
         lw_parse_window<CODEC>(L, parse_slot, ip, op, in_end, cap, lane LW_PROF_PASS);
       }
     } else if (exec_slot >= 0) {
-      lw_execute<WAVES - 1u>(L, (uint32_t)exec_slot, src, dst, wave - 1u, lane, bar LW_PROF_PASS);
+      lw_execute<WAVES - 1u>(L, (uint32_t)exec_slot, src, dst, wave - 1u, lane, bar, nullptr, 0u LW_PROF_PASS);
     }
     __syncthreads();
     exec_slot = -1;
@@ -1046,6 +1068,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
   if (tid == 0) {
     L.arrived = 0;
     L.abort = 0;
+    L.n_ready[0] = L.n_ready[1] = 0;
   }
   __syncthreads();
   LwExecWaves bar = {&L.arrived, &L.abort, 0u, WAVES - PARSERS, lane};
@@ -1134,11 +1157,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_lz_staged_pages(const pqd_decomp
         const LwChainRecord& K = L.chain((b_seq - 1u) & 1u);
         const LwChained c = {K.entry[lane], K.first_elem[lane], K.first_out[lane]};
         lw_elements<CODEC>(L.win(K.win_slot), c, L.elems(c_seq & 1u), &L.window(c_seq & 1u), K.win_slot, K.w0, K.ip, K.op, in_end, cap, lane);
+        if (Lds::READY_TILES) {  // the masks of the window's first tiles, so that the executing waves need not make them
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const LwWindow W = L.window(c_seq & 1u);
+          constexpr uint32_t TILE = lw_tile_bytes(WAVES - PARSERS);
+          uint32_t e_lo = 0, n = 0;
+          for (uint32_t tb = W.o0; tb < W.out_end && n < Lds::READY_TILES; tb += TILE, ++n)
+            lw_tile_masks(L.elems(c_seq & 1u), W.n_elems, W.out_end, tb, TILE, e_lo, L.parse_bits, L.ready(c_seq & 1u)[n], lane);
+          if (lane == 0) L.n_ready[c_seq & 1u] = n;
+        }
         LW_STAMP(3)
       }
     } else if (x_slot >= 0) {
       LW_TICK
-      lw_execute<WAVES - PARSERS>(L, (uint32_t)x_slot, src, dst, wave - PARSERS, lane, bar LW_PROF_PASS);
+      lw_execute<WAVES - PARSERS>(L, (uint32_t)x_slot, src, dst, wave - PARSERS, lane, bar, L.ready((uint32_t)x_slot),
+                                  L.n_ready[x_slot] LW_PROF_PASS);
     }
     __syncthreads();
     x_slot = -1;
