@@ -654,6 +654,60 @@ def test_gpu_damaged_streams(orc, codec_name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["staged16", "staged8", "pipe4", "serial4"])
+@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW"])
+def test_gpu_lz_long_streams_damaged_anywhere(orc, monkeypatch, codec_name, kernel):
+    """Streams of a hundred windows and more (text, bytes that do not compress: literals that reach over many windows;
+    zeros and a short period: matches of many length bytes; small integers), whole and damaged anywhere, cut short, and
+    with a wrong size announced: the windows the kernels have in flight behind a sequence that breaks a rule must not
+    count.  Status, bytes and position as the oracle's, for every kind of kernel."""
+    pa = pytest.importorskip("pyarrow")
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    monkeypatch.setenv("PQD_LZ_PIPE", {"serial": "0", "pipe": "1", "staged": "2"}[kernel.rstrip("0123456789")])
+    monkeypatch.setenv("PQD_LZ_WAVES", kernel.lstrip("pipeserialstaged"))
+    rng = np.random.default_rng(77)
+    words = [bytes(rng.integers(97, 123, int(k), dtype=np.uint8)) for k in rng.integers(2, 10, 500)]
+
+    def content(seed):
+        r = np.random.default_rng(seed)
+        parts = []
+        for kind in r.permutation(6):
+            if kind == 0:
+                parts.append(b" ".join(words[i] for i in r.integers(0, 500, 8000)))
+            elif kind == 1:
+                parts.append(r.integers(0, 256, int(r.integers(3000, 30000)), dtype=np.uint8).tobytes())
+            elif kind == 2:
+                parts.append(bytes(int(r.integers(1000, 70000))))
+            elif kind == 3:
+                parts.append(bytes(r.integers(0, 256, int(r.integers(1, 9)), dtype=np.uint8)) * int(r.integers(500, 6000)))
+            elif kind == 4:
+                parts.append(r.integers(0, 1000, 12000).astype("<i4").tobytes())
+            else:
+                parts.append(np.round(r.normal(size=6000), 2).astype("<f8").tobytes())
+        return b"".join(parts)
+    codec = pa.Codec({"SNAPPY": "snappy", "LZ4_RAW": "lz4_raw"}[codec_name])
+    raws = [content(s) for s in range(6)]
+    streams = [codec.compress(r, asbytes=True) for r in raws]
+    items = [(st, len(r)) for st, r in zip(streams, raws)]
+    for trial in range(54):
+        stream, size = bytearray(streams[trial % 6]), len(raws[trial % 6])
+        for _ in range(int(rng.integers(1, 3))):
+            stream[int(rng.integers(0, len(stream)))] = int(rng.integers(0, 256))
+        if trial % 5 == 0:
+            stream = stream[:int(rng.integers(len(stream) // 2, len(stream)))]
+        if trial % 9 == 0:
+            size = max(0, size + int(rng.integers(-5000, 5000)))
+        items.append((bytes(stream), size))
+    results = run_batch(pq, gh, torch, CODEC_NUM[codec_name], items)
+    for k in range(6):
+        assert results[k][0] == 0 and results[k][1] == raws[k]
+    check_batch(orc, codec_name, items, results)
+
+
+@pytest.mark.gpu
 def test_gpu_stored_parts_and_host_entry(orc):
     import torch
     import parquet_java_amd as pq
