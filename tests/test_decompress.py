@@ -708,6 +708,36 @@ def test_gpu_lz_long_streams_damaged_anywhere(orc, monkeypatch, codec_name, kern
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_pages", [300, 600, 900])
+@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW", "ZSTD"])
+def test_gpu_calls_of_many_pages_take_their_own_kernels(orc, codec_name, n_pages):
+    """The kernel (and its waves per page) follows from the number of pages in the call: calls of 300, 600 and 900 pages,
+    whole and damaged streams mixed, every result as the oracle's."""
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(n_pages)
+    base = [(base64.b64decode(v["compressed"]), v["size"]) for v in VECTORS if v["codec"] == codec_name]
+    items = []
+    for i in range(n_pages):
+        stream, size = base[i % len(base)]
+        if i % 11 == 3:
+            stream = bytearray(stream)
+            stream[int(rng.integers(0, len(stream)))] ^= 1 << int(rng.integers(0, 8))
+            stream = bytes(stream)
+        items.append((stream, size))
+    results = run_batch(pq, gh, torch, CODEC_NUM[codec_name], items)
+    expected = {}
+    for (stream, size), (st, data, used) in zip(items, results):
+        key = (stream, size)
+        if key not in expected:
+            ost, odata, oused = orc.decompress(codec_name, stream, size)
+            expected[key] = (ost, bytes(odata), oused)
+        assert (st, data, used) == expected[key]
+
+
+@pytest.mark.gpu
 def test_gpu_stored_parts_and_host_entry(orc):
     import torch
     import parquet_java_amd as pq
