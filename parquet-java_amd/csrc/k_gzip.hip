@@ -7,7 +7,7 @@
 // (ColumnChunkPageReadStore.java:151-181, :232-262).  A page body is one or more members: a header (ten bytes and
 // the optional FEXTRA / FNAME / FCOMMENT / FHCRC fields), deflate blocks (stored; fixed or dynamic Huffman codes
 // for literals / lengths and for distances), CRC-32 and length of the member's bytes.
-// One wave per page, like the other codecs (pqd_lz_common.hpp: the input staged through LDS, the last 16 KiB
+// One wave per page, like the other codecs (pqd_lz_common.hpp: the input staged through LDS, the last 16 or 8 KiB
 // of output in an LDS ring).  Headers, code construction and the symbol decode run wave-uniformly (every lane
 // computes the same values); a code of up to nine bits is one look-up in a 512-entry table in LDS, longer codes
 // are found length by length from the canonical counts; literals are kept one per lane until 64 are there or
@@ -18,13 +18,18 @@
 // symbol whose bits do not lie inside the stream fails: PQD_DECODE, values_written = the bytes of the symbols
 // in front of it, bytes_consumed = 0.
 // Not HBM-bound: a serial chain of symbols per page; throughput is the number of pages in flight.
+#include <cstdlib>
+
 #include "pqd_device.hpp"
 #include "pqd_kernels.hpp"
 #include "pqd_lz_common.hpp"
 
 namespace pqd {
 
-constexpr uint32_t GZ_RING = 16384;
+// Bytes of output kept in LDS for the matches (farther ones are read back from memory): 16 KiB while all pages of the
+// call are in flight with it (28 KB of LDS a page: five pages a CU), 8 KiB in larger calls (20 KB: eight pages a CU;
+// 1792 pages of 1 MiB: 33 -> 59 GB/s on text, 6 -> 11 on small integers).
+constexpr uint32_t GZ_RING_FEW = 16384, GZ_RING_MANY = 8192, GZ_FEW_PAGES = 1280;
 constexpr uint32_t GZ_FAST_BITS = 9;
 
 struct GzLds {
@@ -248,6 +253,7 @@ __device__ __forceinline__ uint32_t gz_crc32(const PQD_GLOBAL uint8_t* p, uint32
   return acc;
 }
 
+template <uint32_t GZ_RING>
 __global__ __launch_bounds__(64) void k_gzip_pages(const pqd_decompress_desc* __restrict__ descs, pqd_page_result* __restrict__ results,
                                                    uint32_t n_pages) {
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[GZ_RING];
@@ -532,7 +538,12 @@ done:
 
 hipError_t launch_gzip_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_gzip_pages, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  const char* env = getenv("PQD_GZIP_RING");  // 8 / 16: fixes the KiB of output kept in LDS (testing)
+  const int forced = env ? atoi(env) : 0;
+  if (forced == 16 || (forced != 8 && n_pages <= GZ_FEW_PAGES))
+    hipLaunchKernelGGL(k_gzip_pages<GZ_RING_FEW>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  else
+    hipLaunchKernelGGL(k_gzip_pages<GZ_RING_MANY>, dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
   return hipGetLastError();
 }
 

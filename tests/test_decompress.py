@@ -582,6 +582,33 @@ def test_gpu_zstd_pages_with_one_wave(orc, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_gzip_pages_with_the_small_ring(orc, monkeypatch):
+    """The GZIP kernel keeps 16 KiB of a page's output in LDS in calls whose pages are all in flight with that (every
+    test here), 8 KiB in larger ones (matches from farther back are read from memory): the same streams with 8 KiB."""
+    import gzip
+    import torch
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    monkeypatch.setenv("PQD_GZIP_RING", "8")
+    test_gpu_decompresses_library_streams_and_pages(orc, "GZIP")
+    test_gpu_damaged_streams(orc, "GZIP")
+    # matches from 10 to 30 KB back: behind the small ring, inside the format's 32 KiB
+    rng = np.random.default_rng(5)
+    items, raws = [], []
+    for gap in (10_000, 20_000, 30_000):
+        block = rng.integers(0, 256, gap, dtype=np.uint8).tobytes()
+        raw = block + block[:7000] + b"abc" * 100 + block[3000:9000] + block
+        raws.append(raw)
+        items.append((gzip.compress(raw, compresslevel=9, mtime=0), len(raw)))
+    for env in ("8", "16"):
+        monkeypatch.setenv("PQD_GZIP_RING", env)
+        results = run_batch(pq, gh, torch, CODEC_NUM["GZIP"], items)
+        for (st, data, used), raw, (stream, size) in zip(results, raws, items):
+            assert st == 0 and data == raw and used == len(stream)
+        check_batch(orc, "GZIP", items, results)
+
+
+@pytest.mark.gpu
 def test_gpu_snappy_far_copies_in_front_of_literals(orc):
     import torch
     import parquet_java_amd as pq
