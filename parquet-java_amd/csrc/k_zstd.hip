@@ -1111,8 +1111,8 @@ __device__ __forceinline__ void zstd_page(ZShared& sh, uint8_t* s_stage, const p
   }
 }
 
-// PIPE false: one wave per page does everything (calls of many pages: the waves of other pages fill the gaps).  PIPE
-// true: two waves per page, the first decodes, the second moves the bytes.
+// PIPE true: two waves per page, the first decodes, the second moves the bytes.  PIPE false: one wave per page does
+// everything.
 // RING: bytes of output kept in LDS for the matches (farther ones are read back from memory behind a wait for the
 // wave's stores): 8 KiB where seven pages share a CU, more where fewer do.
 template <bool PIPE, uint32_t RING>
@@ -1152,20 +1152,23 @@ __global__ __launch_bounds__(PIPE ? 128 : 64) void k_zstd_pages(const pqd_decomp
   }
 }
 
-// calls of at most this many pages get two waves per page, and the fewer the pages the more of the output in LDS
-constexpr uint32_t ZS_PIPE_MAX_PAGES = 768, ZS_BIG_RING_MAX_PAGES = 512;
+// Two waves per page; the fewer the pages of the call, the more of a page's output is kept in LDS (63 / 47 / 39 KB of
+// LDS a page: two, three, four pages a CU).  One wave per page does no better at any size of call (1792 pages of 1 MiB:
+// 138 / 200 / 202 ms on text / small integers / doubles against 139 / 173 / 179 with two): it is kept for comparison.
+constexpr uint32_t ZS_BIG_RING_MAX_PAGES = 512, ZS_MID_RING_MAX_PAGES = 768;
 
 hipError_t launch_zstd_pages(const pqd_decompress_desc* descs, pqd_page_result* results, uint32_t n_pages, hipStream_t stream) {
   if (n_pages == 0) return hipSuccess;
-  const char* env = getenv("PQD_ZSTD_WAVES");  // 1 / 2: fixes the waves per page (testing)
-  const int forced = env ? atoi(env) : 0;
-  const bool pipe = forced == 2 || (forced != 1 && n_pages <= ZS_PIPE_MAX_PAGES);
-  if (pipe && n_pages <= ZS_BIG_RING_MAX_PAGES)
+  const char* env = getenv("PQD_ZSTD_WAVES");  // 1: one wave per page (testing)
+  const bool pipe = !(env && atoi(env) == 1);
+  if (!pipe)
+    hipLaunchKernelGGL((k_zstd_pages<false, ZS_RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+  else if (n_pages <= ZS_BIG_RING_MAX_PAGES)
     hipLaunchKernelGGL((k_zstd_pages<true, 32768u>), dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
-  else if (pipe)
+  else if (n_pages <= ZS_MID_RING_MAX_PAGES)
     hipLaunchKernelGGL((k_zstd_pages<true, 16384u>), dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
   else
-    hipLaunchKernelGGL((k_zstd_pages<false, ZS_RING>), dim3(n_pages), dim3(64), 0, stream, descs, results, n_pages);
+    hipLaunchKernelGGL((k_zstd_pages<true, ZS_RING>), dim3(n_pages), dim3(128), 0, stream, descs, results, n_pages);
   return hipGetLastError();
 }
 

@@ -574,8 +574,8 @@ def test_gpu_lz_pages_with_other_kernels_and_waves(orc, monkeypatch, codec_name,
 
 @pytest.mark.gpu
 def test_gpu_zstd_pages_with_one_wave(orc, monkeypatch):
-    """The ZSTD kernel gives a page two waves in calls of few pages (the first decodes, the second moves the bytes:
-    every test here), one wave in larger ones: the same streams with one wave."""
+    """The ZSTD kernel gives a page two waves (the first decodes, the second moves the bytes: every test here); the form
+    with one wave per page is kept for comparison: the same streams with it."""
     monkeypatch.setenv("PQD_ZSTD_WAVES", "1")
     test_gpu_decompresses_library_streams_and_pages(orc, "ZSTD")
     test_gpu_damaged_streams(orc, "ZSTD")
