@@ -6,9 +6,10 @@
 // 27-35) and Lz4RawDecompressor.uncompress -> io.airlift.compress.lz4.Lz4Decompressor (codec/
 // Lz4RawDecompressor.java:29-49).  Both formats are a byte-serial stream of "copy these literal bytes" and
 // "repeat `length` bytes from `offset` back" elements: where an element starts is known only when the one before
-// it has been read, and what a match copies may be what the match before it wrote.  A workgroup of four waves per
-// page breaks both chains, 2 KiB of the stream at a time (the parse is the first wave's; the bytes of the output
-// tiles are shared out among all four):
+// it has been read, and what a match copies may be what the match before it wrote.  A workgroup per page breaks both
+// chains, 2 KiB of the stream (a window) at a time; each of the parse's steps is one wave's, the bytes of the output
+// tiles are shared out among the executing waves.  Which waves those are, and whether the steps run one after the
+// other or at once on successive windows, depends on the size of the call (see LW_PIPE16_PAGES below):
 //   parse   (1) the window lies in LDS, a 32-byte segment per lane.  Every lane reads each place of its segment as
 //               if a sequence (Snappy: one element; LZ4: literals + match) started there, last place first, and notes
 //               where the chain from that place leaves the segment, how many elements it passes and how many bytes
@@ -23,11 +24,12 @@
 //   execute (4) The window's output is produced a tile of 4 KiB at a time, a lane per byte: the byte's element from
 //               a bit mask of the element starts; a literal byte is fetched; a match byte becomes a pointer to its
 //               source byte (for a match that overlaps itself: to the first period), or is fetched from memory
-//               when the source lies in front of the tile.  Pointers are then followed by all bytes at once
-//               (p = p of p) until every byte has its value: as many rounds as the logarithm of the longest chain
-//               of matches inside the tile.  The tile leaves in aligned 16-byte stores.
-// Not HBM-bound: instructions per byte bound it (a lone wave per SIMD issues one every four to five cycles; a byte of
-// repetitive text costs about twenty wave-instructions over its 64 lanes, half of them in the pointer rounds).
+//               when the source lies in front of the tile.  Pointers are then followed by all bytes (p = p of p) until
+//               every byte has its value; the waves do not wait for each other between rounds.  The tile leaves in
+//               aligned 16-byte stores.
+// Not HBM-bound: a page's time is the sum (or, with the steps on different waves, the longest) of its serial steps; with
+// thousands of pages in flight the instructions per byte bound it (about twenty wave-instructions per 64 output bytes of
+// repetitive text, half of them in the pointer rounds).
 // Measured and dropped: an element per lane copying its bytes in order, with an LDS ring of the last 32 KiB of output
 // (fewer instructions when matches reach far back, three times slower when most matches read what the 64 elements
 // of their own batch write, as in columns of small numbers and repetitive text).

@@ -314,7 +314,7 @@ def byte_arrays():
     def plain(r):  # PLAIN BYTE_ARRAY: a 4-byte length in front of every value (BinaryPlainValuesReader)
         v = strings(r)
         return np.frombuffer(b"".join(len(x).to_bytes(4, "little") + x for x in v), np.uint8)
-    for label, make, enc, n_p in (("PLAIN BYTE_ARRAY, sorted URLs ~47 B, 2560 x 20000 (320 distinct)", plain, 10, 2560),
+    for label, make, enc, n_p in (("PLAIN BYTE_ARRAY, sorted URLs ~47 B, 2560 x 20000 (320 distinct)", plain, 10, int(os.environ.get("KR_PB_PAGES", "2560"))),
                                   ("DELTA_LENGTH_BYTE_ARRAY, sorted URLs ~47 B, 2560 x 20000 (320 distinct)", dlba, 8, 2560),
                                   ("DELTA_BYTE_ARRAY, sorted URLs ~47 B, 2560 x 20000 (320 distinct)", dba, 9, 2560)):
         made = distinct_pages(make, n_p // 8)  # (building the strings in Python is slow: every page is decoded eight times,
