@@ -735,11 +735,10 @@ def test_gpu_lz_long_streams_damaged_anywhere(orc, monkeypatch, codec_name, kern
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_pages", [300, 600, 900])
-@pytest.mark.parametrize("codec_name", ["SNAPPY", "LZ4_RAW", "ZSTD"])
+@pytest.mark.parametrize("codec_name,n_pages", [(c, n) for c in ("SNAPPY", "LZ4_RAW", "ZSTD") for n in (300, 600, 900)] + [("GZIP", 1400)])
 def test_gpu_calls_of_many_pages_take_their_own_kernels(orc, codec_name, n_pages):
-    """The kernel (and its waves per page) follows from the number of pages in the call: calls of 300, 600 and 900 pages,
-    whole and damaged streams mixed, every result as the oracle's."""
+    """The kernel (its waves per page, the bytes of output it keeps in LDS) follows from the number of pages in the call:
+    calls of 300, 600 and 900 pages (GZIP: 1400), whole and damaged streams mixed, every result as the oracle's."""
     import torch
     import parquet_java_amd as pq
     import gpu_harness as gh
