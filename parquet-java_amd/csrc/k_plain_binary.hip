@@ -26,7 +26,10 @@ namespace pqd {
 
 constexpr uint32_t PB_WIN = 4096;
 constexpr uint32_t PB_NONE = 0xFFFFFFFFu;
-constexpr uint32_t PB_FAIL = 0x00800000u, PB_REL = 0x007FFFFFu;  // a table entry: values on the way << 24 | PB_FAIL | exit - w0 (saturated)
+// a table entry: where the chain from a place leaves its segment, as exit - w0; PB_BEYOND: at or behind the window's
+// end; PB_FAIL: the chain stops inside the segment (a value that cannot be read).  16 bits: with the table, the window
+// and the tiles a page takes 14 KB of LDS, and what counts for a call is how many pages are in flight at once.
+constexpr uint32_t PB_FAIL = 0xFFFFu, PB_BEYOND = 0xFFFEu;
 
 // byte q of the window in LDS: four bytes of padding behind every 64-byte segment, so that the lanes' segments
 // start in different banks
@@ -35,15 +38,15 @@ __device__ __forceinline__ uint32_t pb_at(uint32_t q) { return q + ((q >> 6) << 
 struct PbLds {
   uint8_t win[PB_WIN + 64 + 4 * 66];
   union {
-    uint32_t exits[64 * 65];  // steps 1 and 2: per place, where the chain from it leaves the segment and how many values it passes
+    uint16_t exits[64 * 65];  // steps 1 and 2: per place, where the chain from it leaves the segment
     struct {                  // steps 3 and 4
       uint32_t offs[PB_WIN / 4 + 4];
       __attribute__((aligned(16))) uint8_t out[PB_WIN + 48];
+      uint64_t starts[64];   // per segment: places where a value starts
+      uint64_t lengths[64];  // per segment: bytes of length fields
+      uint32_t before[64];   // values that start in front of the segment (from the page's first)
     } t;
   } u;
-  uint64_t starts[64];   // per segment: places where a value starts
-  uint64_t lengths[64];  // per segment: bytes of length fields
-  uint32_t before[64];   // values that start in front of the segment (from the page's first)
 };
 
 __device__ __forceinline__ uint32_t pb_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -164,33 +167,45 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int p = 4 * g + 3 - u;
-          const uint32_t rel = next[u] - w0 < PB_REL ? next[u] - w0 : PB_REL;  // (at or beyond the window's end: the chain ends there)
-          L.u.exits[lane * 65u + (uint32_t)p] = !ok[u] ? PB_FAIL : (inside[u] ? e_j[u] : rel) + (1u << 24);
+          const uint32_t rel = next[u] - w0 < PB_WIN ? next[u] - w0 : PB_BEYOND;  // (at or beyond the window's end: the chain ends there)
+          L.u.exits[lane * 65u + (uint32_t)p] = (uint16_t)(!ok[u] ? PB_FAIL : inside[u] ? e_j[u] : rel);
         }
       }
     }
     __syncthreads();
     PB_T(1)
-    // ---- 2. the chain through the window
+    // ---- 2. the chain through the window (how many values it passes is counted in step 3)
     const uint32_t idx0 = idx;
-    uint32_t entry = PB_NONE, first_index = 0;
+    uint32_t entry = PB_NONE;
     {
-      uint32_t at = cur, total = idx0;
+      uint32_t at = cur;
       while (at < w0 + PB_WIN) {
         const uint32_t k = (at - w0) >> 6, p = (at - w0) & 63u;
         const uint32_t e = pb_uni(L.u.exits[k * 65u + p]);
-        if (lane == k) {
-          entry = at;
-          first_index = total;
-        }
-        total += e >> 24;
-        if ((e & PB_FAIL) || total >= n) break;
-        at = w0 + (e & PB_REL);
+        if (lane == k) entry = at;
+        if (e >= PB_BEYOND) break;
+        at = w0 + e;
       }
     }
     __syncthreads();  // the tables are done with: their room becomes the tiles
     PB_T(2)
-    // ---- 3. the values of this lane's segment
+    // ---- 3. the values of this lane's segment: counted first (a value that cannot be read ends the count; the chain
+    // may have run on behind the page's last value: lanes that start at or behind it drop out), then listed
+    uint32_t first_index = idx0;
+    {
+      uint32_t count = 0;
+      if (entry != PB_NONE) {
+        uint32_t q = entry;
+        while (q < seg + 64u) {
+          uint32_t next;
+          if (!pb_value_at(q, pb_length_at(L.win, q - w0), data_len, next)) break;
+          ++count;
+          q = next;
+        }
+      }
+      first_index += wave_scan_inclusive(count) - count;
+      if (first_index >= n) entry = PB_NONE;
+    }
     uint64_t starts = 0;
     uint32_t mine = 0, end = 0;
     int32_t fail = PQD_OK;
@@ -244,9 +259,9 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
     if (lane == 0) from_before = spill ? (1u << spill) - 1u : 0u;
     lens |= from_before;
     const uint32_t spill_next = __builtin_popcount(pb_uni((uint32_t)__builtin_amdgcn_readlane((int)behind, 63)));
-    L.starts[lane] = starts;
-    L.lengths[lane] = lens;
-    L.before[lane] = idx0 + inc - mine;
+    L.u.t.starts[lane] = starts;
+    L.u.t.lengths[lane] = lens;
+    L.u.t.before[lane] = idx0 + inc - mine;
     __syncthreads();
     PB_T(3)
     // ---- 4. the value bytes, squeezed together
@@ -260,9 +275,9 @@ __global__ __launch_bounds__(64) void k_plain_byte_array(const pqd_delta_bytes_d
         uint32_t bf[4], byte[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
-          s[u] = L.starts[t0 + u];
-          l[u] = L.lengths[t0 + u];
-          bf[u] = L.before[t0 + u];
+          s[u] = L.u.t.starts[t0 + u];
+          l[u] = L.u.t.lengths[t0 + u];
+          bf[u] = L.u.t.before[t0 + u];
           byte[u] = L.win[pb_at((t0 + u) * 64u + lane)];
         }
 #pragma unroll
