@@ -7,11 +7,12 @@
 // known only once the length of value i is read.  One wave per page takes the page in windows of 4 KiB held in
 // LDS, one 64-byte segment per lane:
 //   1. every lane walks its segment backwards and notes, for each of the 64 places a value could start, where
-//      the chain from there leaves the segment and how many values it passes (a place's entry is that of the
-//      place its own length points at, which lies behind it: one look-up per place);
+//      the chain from there leaves the segment (a place's entry is that of the place its own length points at,
+//      which lies behind it: one look-up per place);
 //   2. the wave follows the chain through the window, one table look-up per segment entered;
-//   3. every lane that was entered walks its segment forward from its entry: the starts of its values
-//      (offsets[i] = start - 4 * i: everything in front of a value but the length fields is value bytes);
+//   3. every lane that was entered walks its segment forward from its entry, twice: first it counts its values (a
+//      prefix sum over the lanes then says which value of the page each lane starts with), then it lists their
+//      starts (offsets[i] = start - 4 * i: everything in front of a value but the length fields is value bytes);
 //   4. the value bytes are squeezed together: byte q of the page goes to q - 4 * (starts at or before q), the
 //      count taken from the lanes' start masks; the window's bytes and offsets leave through LDS tiles in
 //      aligned 16-byte stores.
