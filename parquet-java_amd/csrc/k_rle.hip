@@ -31,6 +31,18 @@ constexpr int WINDOW_SLACK = 48;  // >= 15 (alignment) + 20 (window over-read) r
 constexpr int WINDOW_PIECES = (WINDOW_BYTES + WINDOW_SLACK) / 16;
 constexpr int MAX_SEGS = 512;
 
+// The page decoder's LDS: a window of the stream and the table of its runs.  It shares its room with the whole-page
+// routine's (a page is decoded by one or the other): 31 KB, and with the kernel's registers bounded to 96 five workgroups
+// a CU (36.6 KB, 113-125 registers and four before; the run-heavy shapes follow the number of workgroups in flight:
+// dictionary ids in short runs 541 -> 479 us, read as ints 580 -> 415 us; with three they took 814 us).
+struct RlePageLds {
+  u32x4 win[WINDOW_PIECES];
+  uint32_t seg_start[MAX_SEGS + 1];
+  uint32_t seg_src[MAX_SEGS];
+  uint32_t seg_kind[MAX_SEGS];
+  RleState st;
+};
+
 template <int ELEM, bool HAS_DICT>
 __device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint32_t lo, uint32_t hi,
                                       const uint32_t id[4], uint32_t* oob_at) {
@@ -92,11 +104,12 @@ __device__ __forceinline__ void emit4(const pqd_page_desc& d, uint32_t g0, uint3
 // One page, decoded by the whole workgroup.
 template <int ELEM, bool HAS_DICT>
 __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_result* __restrict__ results, uint32_t page,
-                         u32x4* win4) {  // win4: WINDOW_PIECES pieces of LDS, declared by the kernel
-  __shared__ uint32_t seg_start[MAX_SEGS + 1];
-  __shared__ uint32_t seg_src[MAX_SEGS];
-  __shared__ uint32_t seg_kind[MAX_SEGS];
-  __shared__ RleState st;
+                         RlePageLds& P) {  // P: LDS declared by the kernel
+  u32x4* win4 = P.win;
+  uint32_t* seg_start = P.seg_start;
+  uint32_t* seg_src = P.seg_src;
+  uint32_t* seg_kind = P.seg_kind;
+  RleState& st = P.st;
   const uint32_t* win = reinterpret_cast<const uint32_t*>(win4);
 
   const pqd_page_desc d = descs[page];
@@ -278,7 +291,7 @@ __device__ void rle_page(const pqd_page_desc* __restrict__ descs, pqd_page_resul
 // Dictionary pages with a plan: the same launch then expands the short chunks the sliced gather leaves
 // aside (pool != nullptr; pqd_expand.hpp), in the LDS the page decoder used.
 template <int ELEM, bool HAS_DICT>
-__global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
+__global__ __launch_bounds__(RLE_THREADS, 5) void k_rle_pages(const pqd_page_desc* __restrict__ descs,
                                                            pqd_page_result* __restrict__ results,
                                                            uint32_t n_pages,
                                                            const RlePagePlan* __restrict__ only_fallback,
@@ -286,14 +299,14 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
                                                            const RleSeg* __restrict__ pool, uint32_t pool_chunks,
                                                            const uint32_t* __restrict__ cursor, uint32_t* __restrict__ zero,
                                                            uint32_t zero_words) {
-  constexpr int LDS_PIECES = (sizeof(WholePageLds) + 15) / 16 > WINDOW_PIECES ? (int)((sizeof(WholePageLds) + 15) / 16) : WINDOW_PIECES;
+  constexpr int LDS_PIECES = (int)(((sizeof(WholePageLds) > sizeof(RlePageLds) ? sizeof(WholePageLds) : sizeof(RlePageLds)) + 15) / 16);
   __shared__ u32x4 win4[LDS_PIECES];  // the page decoder's window; the other parts of this kernel use it when no page is being decoded
   // the counter block of the NEXT call on this stream (nothing in this call reads or writes it)
   for (uint32_t i = blockIdx.x * RLE_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * RLE_THREADS) zero[i] = 0u;
   static_assert(sizeof(u32x4) * WINDOW_PIECES >= sizeof(RleSeg) * SEG_CHUNK + 4 * (2 * EX_THREADS * EX_UNITS + 2), "the window holds the expansion's LDS");
   static_assert(RLE_THREADS == EX_THREADS, "one workgroup shape for both parts");
   if (!only_fallback) {
-    if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x, win4);
+    if (blockIdx.x < n_pages) rle_page<ELEM, HAS_DICT>(descs, results, blockIdx.x, *reinterpret_cast<RlePageLds*>(win4));
     return;
   }
   // Pages the plan kernel left to this launch are marked in their plan records (PLAN_F_FALLBACK: for the page decoder;
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_pages(const pqd_page_desc* 
           __syncthreads();
         }
       }
-      rle_page<ELEM, HAS_DICT>(descs, results, page, win4);
+      rle_page<ELEM, HAS_DICT>(descs, results, page, *reinterpret_cast<RlePageLds*>(win4));
     }
     __syncthreads();
   }
@@ -392,7 +405,7 @@ hipError_t launch_rle_pages(const pqd_page_desc* descs, pqd_page_result* results
   const RlePagePlan* pl = reinterpret_cast<const RlePagePlan*>(only_fallback_plans);
   const RleSeg* sp = reinterpret_cast<const RleSeg*>(pool);
   // with a plan: a grid that strides over the left-over pages (few) and, for dictionary pages, over the direct chunks
-  const uint32_t cap = has_dict && sp ? 1024u : 1280u;  // (five workgroups of this kernel fit a CU)
+  const uint32_t cap = 1280u;  // (five workgroups of this kernel fit a CU)
   const dim3 grid(pl && n_pages > cap ? cap : n_pages), block(RLE_THREADS);
   if (!has_dict)
     hipLaunchKernelGGL((k_rle_pages<4, false>), grid, block, 0, stream, descs, results, n_pages, pl, fallback_count, sp, pool_chunks, cursor, zero, zero_words);
