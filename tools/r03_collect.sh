@@ -5,6 +5,8 @@ O=gpurun_out/r03
 cp $O/bench_line.json profiles/r03_bench_line.json
 cp $O/bench_line_profiled.json profiles/r03_bench_line_profiled.json
 python tools/rocpd_stats.py $(find $O/trace -name "*.db" | head -1) profiles/r03_kernel_stats_bench.csv
+python tools/rocpd_stats.py $(find $O/trace_dec -name "*.db" | head -1) profiles/r03_kernel_stats_decompress_1792_pages.csv
+python tools/rocpd_stats.py $(find $O/trace_dec256 -name "*.db" | head -1) profiles/r03_kernel_stats_decompress_256_pages.csv
 python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/pmc_traffic.json
 {
   grep -v "amdgpu.ids" $O/kernel_rates.txt
