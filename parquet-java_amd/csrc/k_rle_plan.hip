@@ -976,7 +976,8 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         if (k >= 2) {
           V = (stage[1].start4 >> 2) - (s0 >> 2);
           S = stage[1].src - c0;
-          ok = ok && V != 0 && (V & 3u) == 0 && V <= (1u << 20);
+          // (the last run may be shorter than the others, not longer: a unit's run is its value index / V)
+          ok = ok && V != 0 && (V & 3u) == 0 && V <= (1u << 20) && v1 - (stage[k - 1].start4 >> 2) <= V;
         }
         bool bad = false;
         for (uint32_t i = tid; i < k; i += PLAN_THREADS)

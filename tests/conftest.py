@@ -11,6 +11,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    # PQD_SEED_SHIFT=n: every numpy generator seeded with an integer gets seed + n, so that the tests which compare
+    # the library with the oracle on seeded inputs run once more on other inputs (fixtures and known answers are not
+    # touched; a test that depends on what one seed happens to produce may then fail for that reason alone).
+    shift = int(os.environ.get("PQD_SEED_SHIFT", "0") or 0)
+    if shift:
+        import numpy as np
+        plain = np.random.default_rng
+
+        def shifted(seed=None, *a, **k):
+            # (codec_inputs.py regenerates the inputs of the committed compressed fixtures: those stay as they are)
+            fixed = sys._getframe(1).f_code.co_filename.endswith("codec_inputs.py")
+            if isinstance(seed, (int, np.integer)) and not fixed:
+                seed = int(seed) + shift
+            return plain(seed, *a, **k)
+
+        np.random.default_rng = shifted
 
 
 @pytest.fixture(scope="session")

@@ -337,3 +337,46 @@ def test_gpu_long_run_heavy_pages_damaged(orc, kind, monkeypatch):
             assert (guard == 0xA5).all(), (mode, i)
     for i, (a, b) in enumerate(zip(results["0"], results[None])):
         assert a[2] == b[2] or a[0] != 0, (i, a[2], b[2])  # bytes consumed (where the page decoded)
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("elem", [4, 8])
+def test_gpu_dictionary_bit_packed_runs_of_growing_length(orc, elem, dict_path):
+    """Bit-packed runs at one distance from each other with a LONGER run behind them (39 groups, then 158; 8, 8, 8,
+    then 100; one run that announces more groups than the stream holds): the chunk is not one of equal runs, whatever
+    the distance between the first two says."""
+    import parquet_java_amd as pq
+    import gpu_harness as gh
+    pq.init(0)
+    rng = np.random.default_rng(5150 + elem)
+    dt = np.int32 if elem == 4 else np.int64
+    pages, expect = [], []
+    for w, groups, dict_len, declared_more in [(1, [39, 158], 7, 0), (1, [39, 158], 7, 5524), (3, [8, 8, 8, 100], 8, 0),
+                                               (4, [16, 40], 16, 0), (7, [5, 5, 64], 128, 0), (12, [4, 4, 4, 4, 63], 4096, 0),
+                                               (16, [3, 30], 65536, 0), (2, [63, 63, 200], 4, 0)]:
+        dic = rng.integers(-10**6, 10**6, dict_len).astype(dt)
+        stream = bytearray([w])
+        n = 0
+        for i, g in enumerate(groups):
+            ids = rng.integers(0, min(dict_len, 1 << w), g * 8)
+            bits = ((ids[:, None] >> np.arange(w)) & 1).astype(np.uint8).reshape(-1)
+            announced = g + (declared_more if i == len(groups) - 1 else 0)
+            stream += _varint((announced << 1) | 1) + np.packbits(bits, bitorder="little").tobytes()
+            n += g * 8
+        data = np.frombuffer(bytes(stream), dtype=np.uint8)
+        for n_page in (n, n - 3):
+            pages.append(gh.Page(data, n_page, pq.ENC_RLE_DICTIONARY, elem, dictionary=dic))
+            expect.append(orc.dict_decode(data, dic, n_page))
+    for i, ((st, written, _, out, guard), (ost, ovals)) in enumerate(zip(gh.decode_pages(pages), expect)):
+        assert ost == 0 and st == ost and written == ovals.size, (i, st, ost, written, ovals.size)
+        assert (out.view(dt)[:written] == ovals).all(), i
+        assert (guard == 0xA5).all()
